@@ -1,0 +1,200 @@
+/*
+ * mmiss.h — C-ABI of libmmiss.so, the MI355X (gfx950) embed-and-retrieve hot path.
+ *
+ * This is the drop-in boundary for ONE path of parsakhaz/multimodal-image-similarity-search:
+ *   image / text -> CLIP tower -> L2-normalise -> cosine top-k over a flat in-HBM index.
+ * The reference has no FFI of its own (it is pure Python over transformers + chromadb); each entry
+ * point below names the reference call site whose arithmetic it replaces (paths relative to the
+ * reference root; "HF:" = transformers/models/clip/).
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, opaque handles. No torch / HIP types in any signature.
+ *   - every data pointer may be a HOST pointer or a DEVICE (HBM) pointer of the handle's GPU; the
+ *     library detects which (hipPointerGetAttributes) and stages host data itself. Outputs likewise.
+ *   - caller allocates every input and output buffer; the library owns only its handles and the HBM
+ *     behind them (weights, index rows, workspaces). It never retains caller memory past a call.
+ *   - every function returns an int status: 0 = MMISS_OK, <0 = error class; mmiss_last_error() returns
+ *     a thread-local message. The Python shim turns non-zero into RuntimeError so the reference's
+ *     `except Exception` paths (backend/app/main.py:803-805,825-827,865-867) behave the same.
+ *   - a handle is internally serialised (one mutex + one HIP stream per handle); different handles are
+ *     independent. Index mutation is safe against a concurrent query on the same handle.
+ *   - there is NO CPU fallback anywhere in this library: with no usable gfx950 device every compute
+ *     entry point fails with MMISS_ERR_HIP.
+ */
+#ifndef MMISS_H
+#define MMISS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMISS_ABI_VERSION 1
+
+enum {
+    MMISS_OK = 0,
+    MMISS_ERR_ARG = -1,         /* bad argument (null, shape, range)                 */
+    MMISS_ERR_HIP = -2,         /* HIP runtime / device failure                      */
+    MMISS_ERR_STATE = -3,       /* call order (e.g. encode before finalize)          */
+    MMISS_ERR_NOMEM = -4,       /* host or device allocation failed                  */
+    MMISS_ERR_UNSUPPORTED = -5, /* shape/dtype the kernels do not cover              */
+    MMISS_ERR_IO = -6           /* file read/write failed (index save/load)          */
+};
+
+/* index storage dtypes */
+enum { MMISS_F32 = 0, MMISS_F16 = 1 };
+
+typedef struct mmiss_encoder mmiss_encoder;
+typedef struct mmiss_index mmiss_index;
+
+/* ---------------------------------------------------------------- misc ------------------------- */
+int mmiss_abi_version(void);
+const char* mmiss_last_error(void);
+/* number of visible HIP devices; does not create a context on any of them */
+int mmiss_device_count(int* count);
+
+/* ---------------------------------------------------------------- encoder ---------------------- */
+/*
+ * Shape-parametric CLIP (two towers + projections). Defaults of HF CLIPConfig() are ViT-B/32
+ * (HF:configuration_clip.py:47-54,97-105,160). The reference HEAD loads a ViT-L/14 LongCLIP with
+ * text_ctx = 248 (backend/app/utils.py:16-17,41-45); both are instances of this struct.
+ * head_dim = hidden / heads must be 64; hidden and mlp must be multiples of 128.
+ */
+typedef struct mmiss_clip_config {
+    int32_t struct_size;   /* = sizeof(mmiss_clip_config), ABI guard */
+    int32_t v_hidden, v_layers, v_heads, v_mlp, v_patch, v_image; /* 768,12,12,3072,32,224 */
+    int32_t t_hidden, t_layers, t_heads, t_mlp, t_vocab, t_ctx;   /* 512,12, 8,2048,49408,77 */
+    int32_t proj_dim;      /* 512 */
+    int32_t eos_token_id;  /* 49407; the legacy value 2 selects argmax(ids) pooling (HF:modeling_clip.py:561-581) */
+    float ln_eps;          /* 1e-5 */
+    int32_t max_batch_image; /* workspace sizing; larger batches are processed in chunks of this */
+    int32_t max_batch_text;
+} mmiss_clip_config;
+
+/* replaces load_clip_model()'s model half — backend/app/utils.py:27-49 */
+int mmiss_encoder_create(const mmiss_clip_config* cfg, int device, mmiss_encoder** out);
+int mmiss_encoder_destroy(mmiss_encoder* enc);
+
+/*
+ * Weights arrive by their HF state_dict key (SURVEY.md §8 a-W), host float32, row-major, e.g.
+ *   "vision_model.encoder.layers.3.self_attn.q_proj.weight"  [768,768]
+ *   "text_model.embeddings.token_embedding.weight"            [49408,512]
+ * Unknown keys ("logit_scale", "*.position_ids") are accepted and ignored (returns MMISS_OK and sets
+ * *used = 0 when used != NULL). The library converts GEMM weights to bf16 and fuses q/k/v.
+ * replaces CLIPModel.from_pretrained(...)'s tensor load — backend/app/utils.py:44
+ */
+int mmiss_encoder_set_weight(mmiss_encoder* enc, const char* hf_key, const float* data, int64_t numel, int* used);
+/* checks that every tensor of both towers was supplied; must precede encode calls */
+int mmiss_encoder_finalize(mmiss_encoder* enc);
+/* run on a caller stream (a hipStream_t passed as void*); NULL = the handle's own stream */
+int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream);
+
+/*
+ * pixels: float32 [B,3,S,S] NCHW, already CLIP-normalised (the output of CLIPImageProcessor,
+ *         HF:image_processing_clip.py:23-34). out: float32 [B,proj_dim], rows unit-norm.
+ * replaces model.get_image_features(**inputs) + "/ norm" — backend/app/utils.py:77-78
+ *          (HF:modeling_clip.py:719-753,613-656)
+ */
+int mmiss_encode_image(mmiss_encoder* enc, const float* pixels, int32_t B, float* out);
+
+/*
+ * pixels_u8: uint8 [B,S,S,3] HWC RGB, already resized+centre-cropped to SxS; the kernel applies
+ * x/255, (x-mean)/std (HF:image_processing_clip.py:23-34; mean/std transformers/utils/constants.py:5-6)
+ * in the patchify prologue. Same output as mmiss_encode_image.
+ */
+int mmiss_encode_image_u8(mmiss_encoder* enc, const uint8_t* pixels_u8, int32_t B, float* out);
+
+/*
+ * ids: int32 [B,T], T <= t_ctx, rows = BOS ... EOS then padding (CLIPTokenizer output,
+ *      backend/app/utils.py:88). out: float32 [B,proj_dim], rows unit-norm. The pooled row is the
+ *      first EOS position, so the padding mask cannot change the result (causal attention).
+ * replaces model.get_text_features(**inputs) + "/ norm" — backend/app/utils.py:97-98
+ *          (HF:modeling_clip.py:683-715,513-586)
+ */
+int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t B, int32_t T, float* out);
+
+/*
+ * Debug tap used by the parity tests to bisect against the oracle's intermediates.
+ * tower: 0 = vision, 1 = text. what: 0 = embeddings (after pre-LN for vision), 1..L = residual
+ * stream after layer i, 100 = pooled+post-LN row (bf16 widened), 101 = projected (pre-normalise).
+ * Copies min(cap, available) floats of the LAST encode call's buffer; *written gets the count.
+ */
+int mmiss_encoder_tap(mmiss_encoder* enc, int tower, int what, float* out, int64_t cap, int64_t* written);
+
+/* ---------------------------------------------------------------- flat index ------------------- */
+/*
+ * Flat cosine index resident in HBM: rows are L2-normalised at add time and stored as f32 or f16.
+ * replaces chromadb's collection with metadata {"hnsw:space":"cosine"} — backend/app/utils.py:104-137
+ */
+int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device, int64_t capacity_hint, mmiss_index** out);
+int mmiss_index_destroy(mmiss_index* idx);
+int mmiss_index_set_stream(mmiss_index* idx, void* hip_stream);
+
+/*
+ * vecs: float32 [n,dim] (any norm > 0). labels: int64 [n], strictly increasing and greater than every
+ * label already stored (they are the tie-break order; the Collection shim hands out sequence numbers).
+ * replaces collection.add(ids, embeddings, ...) — backend/app/main.py:735-740
+ */
+int mmiss_index_add(mmiss_index* idx, const float* vecs, const int64_t* labels, int64_t n);
+/* overwrite the rows of existing labels (labels: host int64 [n]) — collection.update(..., embeddings=) */
+int mmiss_index_update(mmiss_index* idx, const int64_t* labels, const float* vecs, int64_t n);
+/* stable removal (row order = label order is preserved). labels: host. — collection.delete(ids), main.py:1069 */
+int mmiss_index_remove(mmiss_index* idx, const int64_t* labels, int64_t n, int64_t* removed);
+int mmiss_index_clear(mmiss_index* idx);
+/* collection.count() — init_db.py:58 */
+int mmiss_index_count(mmiss_index* idx, int64_t* count);
+/* stored (normalised, storage-rounded) rows widened to f32 [n,dim]; labels: host. Missing label -> MMISS_ERR_ARG */
+int mmiss_index_get(mmiss_index* idx, const int64_t* labels, int64_t n, float* out);
+/* all labels in row order (host int64 [count]) */
+int mmiss_index_labels(mmiss_index* idx, int64_t* out, int64_t cap);
+
+/*
+ * queries: float32 [Q,dim] (any norm > 0; normalised internally). k >= 1.
+ * out_labels int64 [Q,k], out_dist float32 [Q,k] = cosine distance 1 - cos, ascending; ties by label
+ * ascending. out_count int32 [Q] = min(k, count); unused slots hold label -1 / distance +inf.
+ * k larger than count is not an error (the UI's "All" sends 1000 — backend/app/main.py:757).
+ * replaces collection.query(query_embeddings, n_results, include=["metadatas","distances"]) —
+ *          backend/app/main.py:761-765
+ */
+int mmiss_index_query(mmiss_index* idx, const float* queries, int32_t Q, int32_t k,
+                      int64_t* out_labels, float* out_dist, int32_t* out_count);
+
+/* persistence of rows + labels (replaces chroma_data/, backend/app/utils.py:21,113) */
+int mmiss_index_save(mmiss_index* idx, const char* path);
+int mmiss_index_load(mmiss_index* idx, const char* path);
+
+/* ---------------------------------------------------------------- glue kernels ----------------- */
+/*
+ * out[q] = normalize(w * normalize(img[q]) + (1-w) * normalize(txt[q])), float32 [Q,dim].
+ * w is applied as numpy does for `python_float * float32_array`: (float)w and (float)(1.0 - w).
+ * replaces search_multimodal's blend — backend/app/main.py:852-860
+ */
+int mmiss_blend(int device, void* hip_stream, const float* img, const float* txt, double w,
+                int32_t Q, int32_t dim, float* out);
+
+/*
+ * Merge S per-shard result lists (as produced by mmiss_index_query on each shard, then all-gathered)
+ * into the global top-k: dist float32 [S,Q,k], labels int64 [S,Q,k] -> out [Q,k], ordered by
+ * (distance asc, label asc), label -1 entries ignored. No reference analogue (the reference is
+ * single-process); this is the one exchange step of the row-sharded index.
+ */
+int mmiss_merge_topk(int device, void* hip_stream, const float* dist, const int64_t* labels,
+                     int32_t S, int32_t Q, int32_t k, float* out_dist, int64_t* out_labels, int32_t* out_count);
+
+/* ---------------------------------------------------------------- kernel timing ---------------- */
+/*
+ * When enabled every kernel launch of this library is bracketed by HIP events on its stream and
+ * accumulated per kernel class. mmiss_prof_read drains finished events and writes a JSON array
+ *   [{"kernel": "...", "launches": n, "ms": total, "flops": algorithmic, "bytes": algorithmic}, ...]
+ * into buf (NUL-terminated, truncated to cap). Used by bench.py for the roofline object.
+ */
+int mmiss_prof_enable(int on);
+int mmiss_prof_reset(void);
+int mmiss_prof_read(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMISS_H */

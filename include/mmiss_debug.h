@@ -1,0 +1,54 @@
+/*
+ * mmiss_debug.h — kernel-level entry points of libmmiss.so used ONLY by tests/ and bench.py to check
+ * and time single kernels in isolation. Not part of the drop-in boundary. Same pointer conventions
+ * as mmiss.h, except that every pointer here must be a DEVICE pointer of `device` (the tests allocate
+ * them with torch) and calls run on `hip_stream` (NULL = default stream) without synchronising.
+ */
+#ifndef MMISS_DEBUG_H
+#define MMISS_DEBUG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogues of the bf16 MFMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  (A, W bf16 row-major) */
+enum {
+    MMISS_EPI_F32 = 0,             /* out f32 [M,N] = acc                                           */
+    MMISS_EPI_BIAS_BF16 = 1,       /* out bf16 [M,N] = acc + bias[n]            (K3 QKV)            */
+    MMISS_EPI_BIAS_QGELU_BF16 = 2, /* out bf16 [M,N] = quick_gelu(acc + bias)   (K6 FC1)            */
+    MMISS_EPI_BIAS_RESID_F32 = 3,  /* out f32 [M,N] += acc + bias[n]            (K5 out-proj, K7 FC2)*/
+    MMISS_EPI_PATCH_F32 = 4        /* out f32 row (m/G)*T + 1 + m%G = acc + pos[1 + m%G][n] (K1)    */
+};
+
+/* M % 128 == 0, N % 128 == 0, K % 64 == 0. bias f32 [N] (or NULL), aux f32 (pos table for PATCH),
+ * p0 = patches per image G, p1 = tokens per image T (PATCH only). variant selects the tile kernel
+ * (0 = default). */
+int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant, const void* A, const void* W,
+                   void* out, const float* bias, const float* aux, int32_t M, int32_t N, int32_t K,
+                   int32_t p0, int32_t p1);
+
+/* LayerNorm over the last dim: x f32 [M,d] -> out (bf16 if out_bf16 else f32) [M,d]; may be in place for f32 */
+int mmiss_dbg_layernorm(int device, void* hip_stream, const float* x, const float* gamma, const float* beta,
+                        void* out, int32_t out_bf16, int32_t M, int32_t d, float eps);
+
+/* qkv bf16 [B*T, 3*H*64] -> ctx bf16 [B*T, H*64]; softmax(QK^T/8 (+causal)) V per (b, head) */
+int mmiss_dbg_attention(int device, void* hip_stream, const void* qkv, void* ctx, int32_t B, int32_t T,
+                        int32_t H, int32_t causal);
+
+/* pixels f32 [B,3,S,S] -> patches bf16 [B*G*G, Kp] (k = c*P*P + ky*P + kx, zero padded to Kp) */
+int mmiss_dbg_im2col(int device, void* hip_stream, const float* pixels, void* out, int32_t B, int32_t S,
+                     int32_t P, int32_t Kp);
+
+/* HIP-event time of `iters` back-to-back launches of one GEMM (ms per launch) */
+int mmiss_dbg_gemm_time(int device, int epi, int variant, const void* A, const void* W, void* out,
+                        const float* bias, const float* aux, int32_t M, int32_t N, int32_t K,
+                        int32_t p0, int32_t p1, int32_t iters, float* ms_per_launch);
+
+/* record the residual stream after every layer during encode calls (for mmiss_encoder_tap 0..L) */
+struct mmiss_encoder;
+int mmiss_dbg_encoder_record_taps(struct mmiss_encoder* enc, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

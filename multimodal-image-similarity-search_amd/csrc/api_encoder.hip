@@ -1,0 +1,577 @@
+// api_encoder.hip — C-ABI of the CLIP towers: weights by HF state_dict key, batched image / text encode.
+// Launch sequence per layer follows HF:modeling_clip.py:353-383 (pre-LN transformer block).
+#include "common.h"
+#include "gemm_bf16.h"
+#include "encoder_kernels.h"
+#include <map>
+#include <set>
+
+namespace {
+
+// f32 [R,C] -> bf16 rows of stride ldd (dst pre-zeroed where ldd > C)
+__global__ void convert_2d_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t R, int C,
+                                       int ldd) {
+    const int64_t total = R * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        bf16_t v = (bf16_t)src[i];
+        dst[r * ldd + c] = __builtin_bit_cast(uint16_t, v);
+    }
+}
+
+struct LayerW {
+    DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, ln2g, ln2b, w1, b1, w2, b2;
+};
+
+struct Tower {
+    int hidden = 0, layers = 0, heads = 0, mlp = 0, T = 0;  // T = tokens per item
+    std::vector<LayerW> L;
+    DevBuf pos;             // f32 [T, hidden]
+    DevBuf lnf_g, lnf_b;    // post_layernorm / final_layer_norm
+    DevBuf proj;            // bf16 [proj_dim, hidden]
+    // workspaces (lazily allocated for max_batch)
+    int ws_batch = 0;
+    DevBuf x, h, qkv, ctx, u, pooled, proj_out, pool_row, out_stage, taps;
+    int last_B = 0, last_T = 0;
+    int64_t tap_stride = 0;  // floats per recorded tap
+};
+
+// where a state_dict tensor lands
+struct Slot {
+    DevBuf* dst = nullptr;
+    int64_t rows = 0, cols = 0;  // source shape as [rows, cols] (1-D tensors: rows = 1)
+    int64_t dst_row_off = 0;     // destination row offset (q/k/v fusion)
+    int64_t ldd = 0;             // destination row stride in elements
+    bool bf16 = false;
+};
+
+}  // namespace
+
+struct mmiss_encoder {
+    mmiss_clip_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t user_stream = nullptr;
+    bool has_user_stream = false;
+    std::mutex mu;
+    bool finalized = false;
+    bool record_taps = false;
+
+    Tower vis, txt;
+    // vision-only
+    int G = 0, Kp = 0;
+    DevBuf patch_w;   // bf16 [v_hidden, Kp]
+    DevBuf cls;       // f32 [v_hidden]
+    DevBuf pre_g, pre_b;
+    DevBuf patches;   // bf16 [Mpp, Kp]
+    DevBuf pix_stage; // host->device staging of pixels
+    // text-only
+    DevBuf tok;       // f32 [vocab, t_hidden]
+    DevBuf ids_stage;
+
+    DevBuf w_stage;   // set_weight staging
+    std::map<std::string, Slot> slots;
+    std::set<std::string> seen;
+
+    hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
+};
+
+namespace {
+
+int alloc_zero(DevBuf& b, size_t bytes) {
+    MM_TRY(b.alloc(bytes));
+    MM_HIP(hipMemset(b.p, 0, bytes));
+    return MMISS_OK;
+}
+
+int build_tower(mmiss_encoder* e, Tower& tw, const std::string& prefix, int hidden, int layers, int heads, int mlp,
+                int T, int proj_dim, const char* final_ln, const char* proj_key) {
+    tw.hidden = hidden; tw.layers = layers; tw.heads = heads; tw.mlp = mlp; tw.T = T;
+    tw.L.resize(layers);
+    auto add = [&](const std::string& key, DevBuf* dst, int64_t rows, int64_t cols, int64_t row_off, int64_t ldd,
+                   bool bf) {
+        Slot s; s.dst = dst; s.rows = rows; s.cols = cols; s.dst_row_off = row_off; s.ldd = ldd; s.bf16 = bf;
+        e->slots[key] = s;
+    };
+    const int d = hidden;
+    MM_TRY(alloc_zero(tw.pos, (size_t)T * d * 4));
+    add(prefix + ".embeddings.position_embedding.weight", &tw.pos, T, d, 0, d, false);
+    MM_TRY(alloc_zero(tw.lnf_g, (size_t)d * 4));
+    MM_TRY(alloc_zero(tw.lnf_b, (size_t)d * 4));
+    add(prefix + "." + final_ln + ".weight", &tw.lnf_g, 1, d, 0, d, false);
+    add(prefix + "." + final_ln + ".bias", &tw.lnf_b, 1, d, 0, d, false);
+    MM_TRY(alloc_zero(tw.proj, (size_t)proj_dim * d * 2));
+    add(proj_key, &tw.proj, proj_dim, d, 0, d, true);
+    for (int i = 0; i < layers; ++i) {
+        LayerW& L = tw.L[i];
+        const std::string lp = prefix + ".encoder.layers." + std::to_string(i) + ".";
+        MM_TRY(alloc_zero(L.wqkv, (size_t)3 * d * d * 2));
+        MM_TRY(alloc_zero(L.bqkv, (size_t)3 * d * 4));
+        const char* qkv[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            add(lp + "self_attn." + qkv[j] + ".weight", &L.wqkv, d, d, (int64_t)j * d, d, true);
+            add(lp + "self_attn." + qkv[j] + ".bias", &L.bqkv, 1, d, 0, 0, false);
+            e->slots[lp + "self_attn." + qkv[j] + ".bias"].dst_row_off = (int64_t)j * d;  // element offset (1-D)
+        }
+        MM_TRY(alloc_zero(L.wo, (size_t)d * d * 2));
+        MM_TRY(alloc_zero(L.bo, (size_t)d * 4));
+        add(lp + "self_attn.out_proj.weight", &L.wo, d, d, 0, d, true);
+        add(lp + "self_attn.out_proj.bias", &L.bo, 1, d, 0, d, false);
+        MM_TRY(alloc_zero(L.ln1g, (size_t)d * 4)); MM_TRY(alloc_zero(L.ln1b, (size_t)d * 4));
+        MM_TRY(alloc_zero(L.ln2g, (size_t)d * 4)); MM_TRY(alloc_zero(L.ln2b, (size_t)d * 4));
+        add(lp + "layer_norm1.weight", &L.ln1g, 1, d, 0, d, false);
+        add(lp + "layer_norm1.bias", &L.ln1b, 1, d, 0, d, false);
+        add(lp + "layer_norm2.weight", &L.ln2g, 1, d, 0, d, false);
+        add(lp + "layer_norm2.bias", &L.ln2b, 1, d, 0, d, false);
+        MM_TRY(alloc_zero(L.w1, (size_t)mlp * d * 2)); MM_TRY(alloc_zero(L.b1, (size_t)mlp * 4));
+        MM_TRY(alloc_zero(L.w2, (size_t)d * mlp * 2)); MM_TRY(alloc_zero(L.b2, (size_t)d * 4));
+        add(lp + "mlp.fc1.weight", &L.w1, mlp, d, 0, d, true);
+        add(lp + "mlp.fc1.bias", &L.b1, 1, mlp, 0, mlp, false);
+        add(lp + "mlp.fc2.weight", &L.w2, d, mlp, 0, mlp, true);
+        add(lp + "mlp.fc2.bias", &L.b2, 1, d, 0, d, false);
+    }
+    return MMISS_OK;
+}
+
+int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
+    if (tw.ws_batch >= max_batch) return MMISS_OK;
+    const int64_t Mp = round_up((int64_t)max_batch * tw.T, 128);
+    const int64_t Bp = round_up(max_batch, 128);
+    const int d = tw.hidden;
+    MM_TRY(alloc_zero(tw.x, (size_t)Mp * d * 4));
+    MM_TRY(alloc_zero(tw.h, (size_t)Mp * d * 2));
+    MM_TRY(alloc_zero(tw.qkv, (size_t)Mp * 3 * d * 2));
+    MM_TRY(alloc_zero(tw.ctx, (size_t)Mp * d * 2));
+    MM_TRY(alloc_zero(tw.u, (size_t)Mp * tw.mlp * 2));
+    MM_TRY(alloc_zero(tw.pooled, (size_t)Bp * d * 2));
+    MM_TRY(alloc_zero(tw.proj_out, (size_t)Bp * proj_dim * 4));
+    MM_TRY(alloc_zero(tw.pool_row, (size_t)max_batch * 4));
+    MM_TRY(alloc_zero(tw.out_stage, (size_t)max_batch * proj_dim * 4));
+    if (e->record_taps) {
+        tw.tap_stride = Mp * d;
+        MM_TRY(alloc_zero(tw.taps, (size_t)(tw.layers + 1) * tw.tap_stride * 4));
+    }
+    tw.ws_batch = max_batch;
+    return MMISS_OK;
+}
+
+// the transformer stack shared by both towers; x holds the embeddings on entry
+int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) {
+    const int d = tw.hidden, M = B * tw.T;
+    const int Mp = (int)round_up(M, 128);
+    const float eps = e->cfg.ln_eps;
+    auto tap = [&](int which) -> int {
+        if (e->record_taps && tw.taps.p)
+            MM_HIP(hipMemcpyAsync(tw.taps.as<float>() + (size_t)which * tw.tap_stride, tw.x.p, (size_t)M * d * 4,
+                                  hipMemcpyDeviceToDevice, st));
+        return MMISS_OK;
+    };
+    MM_TRY(tap(0));
+    for (int l = 0; l < tw.layers; ++l) {
+        LayerW& L = tw.L[l];
+        MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
+                                d, eps));
+        GemmEpi ep{};
+        ep.out = tw.qkv.p; ep.bias = L.bqkv.as<float>(); ep.ldo = 3 * d; ep.m_valid = M;
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, 0, tw.h.p, L.wqkv.p, ep, Mp, 3 * d, d));
+        MM_TRY(launch_attention(st, tw.qkv.p, tw.ctx.p, B, tw.T, tw.heads, causal));
+        ep = GemmEpi{};
+        ep.out = tw.x.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = M;
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, 0, tw.ctx.p, L.wo.p, ep, Mp, d, d));
+        MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
+                                d, eps));
+        ep = GemmEpi{};
+        ep.out = tw.u.p; ep.bias = L.b1.as<float>(); ep.ldo = tw.mlp; ep.m_valid = M;
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, 0, tw.h.p, L.w1.p, ep, Mp, tw.mlp, d));
+        ep = GemmEpi{};
+        ep.out = tw.x.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = M;
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, 0, tw.u.p, L.w2.p, ep, Mp, d, tw.mlp));
+        MM_TRY(tap(l + 1));
+    }
+    return MMISS_OK;
+}
+
+// K8: pooled row -> final LayerNorm -> projection (no bias) -> L2 normalise
+int run_head(mmiss_encoder* e, Tower& tw, int B, float* out_dev, hipStream_t st) {
+    const int d = tw.hidden, P = e->cfg.proj_dim;
+    const int Bp = (int)round_up(B, 128);
+    MM_TRY(launch_layernorm(st, tw.x.as<float>(), tw.lnf_g.as<float>(), tw.lnf_b.as<float>(), tw.pooled.p, true,
+                            tw.pool_row.as<int32_t>(), B, d, e->cfg.ln_eps));
+    GemmEpi ep{};
+    ep.out = tw.proj_out.p; ep.ldo = P; ep.m_valid = B;
+    MM_TRY(launch_gemm(st, MMISS_EPI_F32, 0, tw.pooled.p, tw.proj.p, ep, Bp, P, d));
+    {
+        MM_PROF("l2norm_rows", st, 3.0 * B * P, 8.0 * B * P);
+        hipLaunchKernelGGL(l2norm_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, st, tw.proj_out.as<float>(), out_dev, B,
+                           P, P);
+    }
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B, float* out_dev, hipStream_t st) {
+    Tower& tw = e->vis;
+    const int d = tw.hidden, S = e->cfg.v_image, P = e->cfg.v_patch;
+    const int Mpatch = B * e->G * e->G;
+    const int Mpp = (int)round_up(Mpatch, 128);
+    MM_TRY(launch_im2col(st, pix_dev, src_u8, e->patches.p, B, S, P, e->Kp));
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, st, tw.x.as<float>(),
+                       e->cls.as<float>(), tw.pos.as<float>(), B, tw.T, d);
+    GemmEpi ep{};
+    ep.out = tw.x.p; ep.aux = tw.pos.as<float>(); ep.ldo = d; ep.m_valid = Mpatch; ep.p0 = e->G * e->G; ep.p1 = tw.T;
+    MM_TRY(launch_gemm(st, MMISS_EPI_PATCH_F32, 0, e->patches.p, e->patch_w.p, ep, Mpp, d, e->Kp));
+    // pre_layrnorm, in place on the fp32 residual stream (HF:modeling_clip.py:640)
+    MM_TRY(launch_layernorm(st, tw.x.as<float>(), e->pre_g.as<float>(), e->pre_b.as<float>(), tw.x.p, false, nullptr,
+                            B * tw.T, d, e->cfg.ln_eps));
+    MM_TRY(run_layers(e, tw, B, false, st));
+    hipLaunchKernelGGL(vision_pool_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, tw.pool_row.as<int32_t>(), B,
+                       tw.T);
+    MM_TRY(run_head(e, tw, B, out_dev, st));
+    tw.last_B = B;
+    tw.last_T = tw.T;
+    return MMISS_OK;
+}
+
+int encode_text_chunk(mmiss_encoder* e, const int32_t* ids_dev, int B, int T, float* out_dev, hipStream_t st) {
+    Tower& tw = e->txt;
+    const int d = tw.hidden;
+    const int savedT = tw.T;
+    tw.T = T;  // shorter-than-ctx sequences run at their own length (positions 0..T-1)
+    hipLaunchKernelGGL(text_embed_kernel, dim3(B), dim3(256), 0, st, ids_dev, e->tok.as<float>(), tw.pos.as<float>(),
+                       tw.x.as<float>(), tw.pool_row.as<int32_t>(), T, d, e->cfg.t_vocab, e->cfg.eos_token_id);
+    int rc = run_layers(e, tw, B, true, st);
+    if (rc == MMISS_OK) rc = run_head(e, tw, B, out_dev, st);
+    tw.T = savedT;
+    tw.last_B = B;
+    tw.last_T = T;
+    return rc;
+}
+
+int finish_call(mmiss_encoder* e, hipStream_t st, bool must_sync) {
+    if (must_sync || !e->has_user_stream) MM_HIP(hipStreamSynchronize(st));
+    return MMISS_OK;
+}
+
+}  // namespace
+
+// ================================================================================================ C-ABI
+extern "C" int mmiss_encoder_create(const mmiss_clip_config* cfg, int device, mmiss_encoder** out) {
+    if (!cfg || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_encoder_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(mmiss_clip_config))
+        MM_FAIL(MMISS_ERR_ARG, "mmiss_clip_config.struct_size %d != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(mmiss_clip_config));
+    auto bad_tower = [](int hidden, int layers, int heads, int mlp) {
+        return hidden <= 0 || layers <= 0 || heads <= 0 || hidden != heads * 64 || hidden % 128 || mlp % 128 ||
+               hidden > 1024 || mlp <= 0;
+    };
+    if (bad_tower(cfg->v_hidden, cfg->v_layers, cfg->v_heads, cfg->v_mlp) ||
+        bad_tower(cfg->t_hidden, cfg->t_layers, cfg->t_heads, cfg->t_mlp))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED,
+                "tower shape unsupported: need head_dim 64, hidden %% 128 == 0, hidden <= 1024, mlp %% 128 == 0");
+    if (cfg->v_patch <= 0 || cfg->v_image <= 0 || cfg->v_image % cfg->v_patch)
+        MM_FAIL(MMISS_ERR_ARG, "image size %d not a multiple of patch %d", cfg->v_image, cfg->v_patch);
+    if (cfg->proj_dim <= 0 || cfg->proj_dim % 128) MM_FAIL(MMISS_ERR_UNSUPPORTED, "proj_dim %d must be a multiple of 128", cfg->proj_dim);
+    const int G = cfg->v_image / cfg->v_patch;
+    if (G * G + 1 > 288 || cfg->t_ctx > 288 || cfg->t_ctx <= 0)
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "sequence length > 288 tokens is not supported by the attention kernel");
+    if (cfg->t_vocab <= 0) MM_FAIL(MMISS_ERR_ARG, "bad vocab size");
+    MM_TRY(mmiss_use_device(device));
+
+    mmiss_encoder* e = new (std::nothrow) mmiss_encoder();
+    if (!e) MM_FAIL(MMISS_ERR_NOMEM, "out of host memory");
+    e->cfg = *cfg;
+    if (e->cfg.max_batch_image <= 0) e->cfg.max_batch_image = 256;
+    if (e->cfg.max_batch_text <= 0) e->cfg.max_batch_text = 256;
+    if (e->cfg.ln_eps <= 0.f) e->cfg.ln_eps = 1e-5f;
+    e->device = device;
+    e->G = G;
+    e->Kp = (int)round_up(3 * cfg->v_patch * cfg->v_patch, 64);
+    int rc = MMISS_OK;
+    do {
+        if (hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) {
+            mmiss_set_error("hipStreamCreate failed");
+            rc = MMISS_ERR_HIP;
+            break;
+        }
+        rc = build_tower(e, e->vis, "vision_model", cfg->v_hidden, cfg->v_layers, cfg->v_heads, cfg->v_mlp, G * G + 1,
+                         cfg->proj_dim, "post_layernorm", "visual_projection.weight");
+        if (rc) break;
+        rc = build_tower(e, e->txt, "text_model", cfg->t_hidden, cfg->t_layers, cfg->t_heads, cfg->t_mlp, cfg->t_ctx,
+                         cfg->proj_dim, "final_layer_norm", "text_projection.weight");
+        if (rc) break;
+        const int dv = cfg->v_hidden, PP3 = 3 * cfg->v_patch * cfg->v_patch;
+        if ((rc = alloc_zero(e->patch_w, (size_t)dv * e->Kp * 2))) break;
+        if ((rc = alloc_zero(e->cls, (size_t)dv * 4))) break;
+        if ((rc = alloc_zero(e->pre_g, (size_t)dv * 4))) break;
+        if ((rc = alloc_zero(e->pre_b, (size_t)dv * 4))) break;
+        if ((rc = alloc_zero(e->tok, (size_t)cfg->t_vocab * cfg->t_hidden * 4))) break;
+        Slot s;
+        s = Slot(); s.dst = &e->patch_w; s.rows = dv; s.cols = PP3; s.ldd = e->Kp; s.bf16 = true;
+        e->slots["vision_model.embeddings.patch_embedding.weight"] = s;
+        s = Slot(); s.dst = &e->cls; s.rows = 1; s.cols = dv; s.ldd = dv;
+        e->slots["vision_model.embeddings.class_embedding"] = s;
+        s = Slot(); s.dst = &e->pre_g; s.rows = 1; s.cols = dv; s.ldd = dv;
+        e->slots["vision_model.pre_layrnorm.weight"] = s;  // (sic) the HF key really is "pre_layrnorm"
+        s = Slot(); s.dst = &e->pre_b; s.rows = 1; s.cols = dv; s.ldd = dv;
+        e->slots["vision_model.pre_layrnorm.bias"] = s;
+        s = Slot(); s.dst = &e->tok; s.rows = cfg->t_vocab; s.cols = cfg->t_hidden; s.ldd = cfg->t_hidden;
+        e->slots["text_model.embeddings.token_embedding.weight"] = s;
+    } while (0);
+    if (rc != MMISS_OK) {
+        if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_encoder_destroy(mmiss_encoder* enc) {
+    if (!enc) return MMISS_OK;
+    (void)hipSetDevice(enc->device);
+    (void)hipDeviceSynchronize();
+    if (enc->own_stream) (void)hipStreamDestroy(enc->own_stream);
+    delete enc;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream) {
+    if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    enc->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
+    enc->has_user_stream = hip_stream != nullptr;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_encoder_set_weight(mmiss_encoder* enc, const char* hf_key, const float* data, int64_t numel,
+                                        int* used) {
+    if (!enc || !hf_key || !data) MM_FAIL(MMISS_ERR_ARG, "mmiss_encoder_set_weight: null argument");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    MM_TRY(mmiss_use_device(enc->device));
+    auto it = enc->slots.find(hf_key);
+    if (it == enc->slots.end()) {
+        if (used) *used = 0;
+        return MMISS_OK;
+    }
+    const Slot& s = it->second;
+    if (numel != s.rows * s.cols)
+        MM_FAIL(MMISS_ERR_ARG, "weight %s: got %lld elements, expected %lld (%lld x %lld)", hf_key, (long long)numel,
+                (long long)(s.rows * s.cols), (long long)s.rows, (long long)s.cols);
+    hipStream_t st = enc->own_stream;
+    const float* src = data;
+    if (!mmiss_is_device_ptr(data)) {
+        MM_TRY(enc->w_stage.ensure((size_t)numel * 4));
+        MM_HIP(hipMemcpyAsync(enc->w_stage.p, data, (size_t)numel * 4, hipMemcpyHostToDevice, st));
+        src = enc->w_stage.as<float>();
+    }
+    if (s.bf16) {
+        uint16_t* dst = s.dst->as<uint16_t>() + s.dst_row_off * s.ldd;
+        const int grid = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
+        hipLaunchKernelGGL(convert_2d_bf16_kernel, dim3(grid), dim3(256), 0, st, src, dst, s.rows, (int)s.cols,
+                           (int)s.ldd);
+        MM_HIP(hipGetLastError());
+    } else {
+        // 1-D slots use dst_row_off as an element offset (ldd may be 0 for fused biases)
+        float* dst = s.dst->as<float>() + (s.rows == 1 ? s.dst_row_off : s.dst_row_off * s.ldd);
+        MM_HIP(hipMemcpyAsync(dst, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, st));
+    }
+    MM_HIP(hipStreamSynchronize(st));
+    enc->seen.insert(hf_key);
+    if (used) *used = 1;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_encoder_finalize(mmiss_encoder* enc) {
+    if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    std::string missing;
+    int n_missing = 0;
+    for (auto& kv : enc->slots)
+        if (!enc->seen.count(kv.first)) {
+            if (n_missing < 4) missing += (n_missing ? ", " : "") + kv.first;
+            ++n_missing;
+        }
+    if (n_missing)
+        MM_FAIL(MMISS_ERR_STATE, "mmiss_encoder_finalize: %d weight tensors missing (%s%s)", n_missing, missing.c_str(),
+                n_missing > 4 ? ", ..." : "");
+    enc->finalized = true;
+    return MMISS_OK;
+}
+
+static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8, int32_t B, float* out) {
+    if (!enc || !pixels || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_encode_image: null argument");
+    if (B < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_encode_image: B = %d", B);
+    std::lock_guard<std::mutex> lk(enc->mu);
+    if (!enc->finalized) MM_FAIL(MMISS_ERR_STATE, "mmiss_encode_image before mmiss_encoder_finalize");
+    if (B == 0) return MMISS_OK;
+    MM_TRY(mmiss_use_device(enc->device));
+    hipStream_t st = enc->stream();
+    const int maxb = enc->cfg.max_batch_image, S = enc->cfg.v_image, P = enc->cfg.proj_dim;
+    MM_TRY(ensure_tower_ws(enc, enc->vis, maxb, P));
+    if (!enc->patches.p) {
+        const int64_t Mpp = round_up((int64_t)maxb * enc->G * enc->G, 128);
+        MM_TRY(alloc_zero(enc->patches, (size_t)Mpp * enc->Kp * 2));
+    }
+    const bool in_dev = mmiss_is_device_ptr(pixels), out_dev = mmiss_is_device_ptr(out);
+    const size_t img_bytes = (size_t)3 * S * S * (src_u8 ? 1 : 4);
+    if (!in_dev) MM_TRY(enc->pix_stage.ensure(img_bytes * maxb));
+    for (int b0 = 0; b0 < B; b0 += maxb) {
+        const int nb = (B - b0 < maxb) ? B - b0 : maxb;
+        const char* src = reinterpret_cast<const char*>(pixels) + (size_t)b0 * img_bytes;
+        if (!in_dev) {
+            MM_HIP(hipMemcpyAsync(enc->pix_stage.p, src, img_bytes * nb, hipMemcpyHostToDevice, st));
+            src = enc->pix_stage.as<char>();
+        }
+        float* dst = out_dev ? out + (size_t)b0 * P : enc->vis.out_stage.as<float>();
+        MM_TRY(encode_image_chunk(enc, src, src_u8, nb, dst, st));
+        if (!out_dev) {
+            MM_HIP(hipMemcpyAsync(out + (size_t)b0 * P, dst, (size_t)nb * P * 4, hipMemcpyDeviceToHost, st));
+            MM_HIP(hipStreamSynchronize(st));
+        } else if (!in_dev) {
+            MM_HIP(hipStreamSynchronize(st));  // the staging buffer is reused by the next chunk
+        }
+    }
+    return finish_call(enc, st, !out_dev);
+}
+
+extern "C" int mmiss_encode_image(mmiss_encoder* enc, const float* pixels, int32_t B, float* out) {
+    return encode_image_impl(enc, pixels, false, B, out);
+}
+
+extern "C" int mmiss_encode_image_u8(mmiss_encoder* enc, const uint8_t* pixels_u8, int32_t B, float* out) {
+    return encode_image_impl(enc, pixels_u8, true, B, out);
+}
+
+extern "C" int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t B, int32_t T, float* out) {
+    if (!enc || !ids || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_encode_text: null argument");
+    if (B < 0 || T <= 0 || T > enc->cfg.t_ctx)
+        MM_FAIL(MMISS_ERR_ARG, "mmiss_encode_text: B=%d T=%d (context length is %d)", B, T, enc->cfg.t_ctx);
+    std::lock_guard<std::mutex> lk(enc->mu);
+    if (!enc->finalized) MM_FAIL(MMISS_ERR_STATE, "mmiss_encode_text before mmiss_encoder_finalize");
+    if (B == 0) return MMISS_OK;
+    MM_TRY(mmiss_use_device(enc->device));
+    hipStream_t st = enc->stream();
+    const int maxb = enc->cfg.max_batch_text, P = enc->cfg.proj_dim;
+    MM_TRY(ensure_tower_ws(enc, enc->txt, maxb, P));
+    const bool in_dev = mmiss_is_device_ptr(ids), out_dev = mmiss_is_device_ptr(out);
+    if (!in_dev) MM_TRY(enc->ids_stage.ensure((size_t)maxb * enc->cfg.t_ctx * 4));
+    for (int b0 = 0; b0 < B; b0 += maxb) {
+        const int nb = (B - b0 < maxb) ? B - b0 : maxb;
+        const int32_t* src = ids + (size_t)b0 * T;
+        if (!in_dev) {
+            MM_HIP(hipMemcpyAsync(enc->ids_stage.p, src, (size_t)nb * T * 4, hipMemcpyHostToDevice, st));
+            src = enc->ids_stage.as<int32_t>();
+        }
+        float* dst = out_dev ? out + (size_t)b0 * P : enc->txt.out_stage.as<float>();
+        MM_TRY(encode_text_chunk(enc, src, nb, T, dst, st));
+        if (!out_dev) {
+            MM_HIP(hipMemcpyAsync(out + (size_t)b0 * P, dst, (size_t)nb * P * 4, hipMemcpyDeviceToHost, st));
+            MM_HIP(hipStreamSynchronize(st));
+        } else if (!in_dev) {
+            MM_HIP(hipStreamSynchronize(st));
+        }
+    }
+    return finish_call(enc, st, !out_dev);
+}
+
+extern "C" int mmiss_dbg_encoder_record_taps(mmiss_encoder* enc, int on) {
+    if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    enc->record_taps = on != 0;
+    // force workspace re-allocation with the tap buffer
+    if (on) { enc->vis.ws_batch = 0; enc->txt.ws_batch = 0; }
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_encoder_tap(mmiss_encoder* enc, int tower, int what, float* out, int64_t cap, int64_t* written) {
+    if (!enc || !out || cap < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_encoder_tap: bad argument");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    MM_TRY(mmiss_use_device(enc->device));
+    Tower& tw = tower == 0 ? enc->vis : enc->txt;
+    if (tw.last_B <= 0) MM_FAIL(MMISS_ERR_STATE, "mmiss_encoder_tap: no encode call yet on this tower");
+    hipStream_t st = enc->stream();
+    MM_HIP(hipStreamSynchronize(st));
+    const int B = tw.last_B, d = tw.hidden, P = enc->cfg.proj_dim;
+    int64_t n = 0;
+    const bool out_dev = mmiss_is_device_ptr(out);
+    DevBuf tmp;
+    if (what >= 0 && what <= tw.layers) {
+        if (!tw.taps.p) MM_FAIL(MMISS_ERR_STATE, "taps not recorded: call mmiss_dbg_encoder_record_taps(enc, 1) first");
+        n = (int64_t)B * tw.last_T * d;  // rows are packed at the last call's sequence length
+        if (n > cap) n = cap;
+        const float* src = tw.taps.as<float>() + (size_t)what * tw.tap_stride;
+        MM_HIP(hipMemcpy(out, src, (size_t)n * 4, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    } else if (what == 100) {
+        n = (int64_t)B * d;
+        if (n > cap) n = cap;
+        MM_TRY(tmp.alloc((size_t)n * 4));
+        hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(256), dim3(256), 0, st, tw.pooled.as<uint16_t>(), tmp.as<float>(), n);
+        MM_HIP(hipStreamSynchronize(st));
+        MM_HIP(hipMemcpy(out, tmp.p, (size_t)n * 4, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    } else if (what == 101) {
+        n = (int64_t)B * P;
+        if (n > cap) n = cap;
+        MM_HIP(hipMemcpy(out, tw.proj_out.p, (size_t)n * 4, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    } else {
+        MM_FAIL(MMISS_ERR_ARG, "mmiss_encoder_tap: unknown tap %d", what);
+    }
+    if (written) *written = n;
+    return MMISS_OK;
+}
+
+// ================================================================================================ debug ABI
+extern "C" int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant, const void* A, const void* W,
+                              void* out, const float* bias, const float* aux, int32_t M, int32_t N, int32_t K,
+                              int32_t p0, int32_t p1) {
+    if (!A || !W || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_gemm: null pointer");
+    MM_TRY(mmiss_use_device(device));
+    GemmEpi ep{};
+    ep.out = out; ep.bias = bias; ep.aux = aux; ep.ldo = N; ep.m_valid = M; ep.p0 = p0; ep.p1 = p1;
+    return launch_gemm(reinterpret_cast<hipStream_t>(hip_stream), epi, variant, A, W, ep, M, N, K);
+}
+
+extern "C" int mmiss_dbg_gemm_time(int device, int epi, int variant, const void* A, const void* W, void* out,
+                                   const float* bias, const float* aux, int32_t M, int32_t N, int32_t K, int32_t p0,
+                                   int32_t p1, int32_t iters, float* ms_per_launch) {
+    if (!A || !W || !out || !ms_per_launch || iters <= 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_gemm_time: bad argument");
+    MM_TRY(mmiss_use_device(device));
+    GemmEpi ep{};
+    ep.out = out; ep.bias = bias; ep.aux = aux; ep.ldo = N; ep.m_valid = M; ep.p0 = p0; ep.p1 = p1;
+    hipEvent_t e0, e1;
+    MM_HIP(hipEventCreate(&e0));
+    MM_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) MM_TRY(launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K));
+    MM_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) MM_TRY(launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K));
+    MM_HIP(hipEventRecord(e1, nullptr));
+    MM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / iters;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_dbg_layernorm(int device, void* hip_stream, const float* x, const float* gamma, const float* beta,
+                                   void* out, int32_t out_bf16, int32_t M, int32_t d, float eps) {
+    if (!x || !gamma || !beta || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_layernorm: null pointer");
+    MM_TRY(mmiss_use_device(device));
+    return launch_layernorm(reinterpret_cast<hipStream_t>(hip_stream), x, gamma, beta, out, out_bf16 != 0, nullptr, M, d,
+                            eps);
+}
+
+extern "C" int mmiss_dbg_attention(int device, void* hip_stream, const void* qkv, void* ctx, int32_t B, int32_t T,
+                                   int32_t H, int32_t causal) {
+    if (!qkv || !ctx) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_attention: null pointer");
+    MM_TRY(mmiss_use_device(device));
+    return launch_attention(reinterpret_cast<hipStream_t>(hip_stream), qkv, ctx, B, T, H, causal != 0);
+}
+
+extern "C" int mmiss_dbg_im2col(int device, void* hip_stream, const float* pixels, void* out, int32_t B, int32_t S,
+                                int32_t P, int32_t Kp) {
+    if (!pixels || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_im2col: null pointer");
+    MM_TRY(mmiss_use_device(device));
+    return launch_im2col(reinterpret_cast<hipStream_t>(hip_stream), pixels, false, out, B, S, P, Kp);
+}

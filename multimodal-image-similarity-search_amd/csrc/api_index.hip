@@ -1,0 +1,592 @@
+// api_index.hip — C-ABI of the flat cosine index (the chromadb Collection's numeric half) and the two
+// stateless glue kernels (blend, shard merge).
+#include "common.h"
+#include "retrieval_kernels.h"
+#include <algorithm>
+
+struct mmiss_index {
+    int dim = 0, dtype = MMISS_F32, device = 0, elt = 4;
+    hipStream_t own_stream = nullptr, user_stream = nullptr;
+    bool has_user_stream = false;
+    std::mutex mu;
+    int64_t count = 0, capacity = 0;
+    DevBuf rows, labels_d;
+    std::vector<int64_t> labels_h;
+    // scratch
+    DevBuf stage, qn, qs, qstage, lists_s, lists_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, tmp_rows, tmp_labels;
+    hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
+};
+
+namespace {
+
+int index_reserve(mmiss_index* ix, int64_t need, hipStream_t st) {
+    if (need <= ix->capacity) return MMISS_OK;
+    int64_t cap = ix->capacity > 0 ? ix->capacity : 1024;
+    while (cap < need) cap *= 2;
+    DevBuf nr, nl;
+    MM_TRY(nr.alloc((size_t)cap * ix->dim * ix->elt));
+    MM_TRY(nl.alloc((size_t)cap * 8));
+    if (ix->count > 0) {
+        MM_HIP(hipMemcpyAsync(nr.p, ix->rows.p, (size_t)ix->count * ix->dim * ix->elt, hipMemcpyDeviceToDevice, st));
+        MM_HIP(hipMemcpyAsync(nl.p, ix->labels_d.p, (size_t)ix->count * 8, hipMemcpyDeviceToDevice, st));
+        MM_HIP(hipStreamSynchronize(st));
+    }
+    std::swap(ix->rows.p, nr.p); std::swap(ix->rows.bytes, nr.bytes);
+    std::swap(ix->labels_d.p, nl.p); std::swap(ix->labels_d.bytes, nl.bytes);
+    ix->capacity = cap;
+    return MMISS_OK;
+}
+
+int launch_normalize(mmiss_index* ix, const float* src_dev, void* dst, int64_t n, hipStream_t st) {
+    if (n <= 0) return MMISS_OK;
+    MM_PROF("normalize_rows", st, 4.0 * n * ix->dim, (double)n * ix->dim * (4 + ix->elt));
+    const int grid = (int)((n + 3) / 4);
+    if (ix->dtype == MMISS_F16)
+        hipLaunchKernelGGL(normalize_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, src_dev, (_Float16*)dst, n, ix->dim);
+    else
+        hipLaunchKernelGGL(normalize_rows_kernel<float>, dim3(grid), dim3(256), 0, st, src_dev, (float*)dst, n, ix->dim);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+// host copy of a (host or device) int64 array
+int fetch_i64(const int64_t* p, int64_t n, std::vector<int64_t>& out) {
+    out.resize((size_t)n);
+    if (n == 0) return MMISS_OK;
+    if (mmiss_is_device_ptr(p))
+        MM_HIP(hipMemcpy(out.data(), p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    else
+        memcpy(out.data(), p, (size_t)n * 8);
+    return MMISS_OK;
+}
+
+int64_t find_row(const mmiss_index* ix, int64_t label) {
+    auto it = std::lower_bound(ix->labels_h.begin(), ix->labels_h.end(), label);
+    if (it == ix->labels_h.end() || *it != label) return -1;
+    return it - ix->labels_h.begin();
+}
+
+template <typename T, int NQT, int CAP>
+int launch_scan_t(hipStream_t st, const ScanArgs& a, int slabs, int qtiles, int lds) {
+    static int attr_lds = 0;
+    if (lds > attr_lds) {
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_kernel<T, NQT, CAP>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((scan_topk_kernel<T, NQT, CAP>), dim3(slabs, qtiles), dim3(256), lds, st, a);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+struct ScanPlan {
+    int nqt, cap, lds, slabs, qtiles, tiles_per_block;
+};
+
+ScanPlan plan_scan(int D, int elt, int Q, int kp, int64_t N) {
+    ScanPlan p{};
+    const int limit = 160 * 1024;
+    p.nqt = 1; p.cap = 64;
+    if (kp <= 16 && Q > 16) {
+        for (int nqt : {4, 2}) {
+            const int NQ = 16 * nqt;
+            const int lds = (((NQ * (D * elt + 16)) + 15) & ~15) + 2 * 4 * NQ * 32 * 4 + 2 * 4 * NQ * 4;
+            if (lds <= limit && (Q > 16 * nqt / 2)) { p.nqt = nqt; p.cap = 32; break; }
+        }
+    }
+    const int NQ = 16 * p.nqt;
+    p.lds = (((NQ * (D * elt + 16)) + 15) & ~15) + 2 * 4 * NQ * p.cap * 4 + 2 * 4 * NQ * 4;
+    p.qtiles = (Q + NQ - 1) / NQ;
+    const int64_t ntiles = (N + 15) / 16;
+    const int blocks_per_cu = std::max(1, std::min(8, limit / p.lds));
+    int64_t target = (int64_t)256 * blocks_per_cu * 2 / p.qtiles;
+    if (target < 1) target = 1;
+    if (target > 1024) target = 1024;
+    int64_t tpb = (ntiles + target - 1) / target;
+    tpb = (tpb + 3) / 4 * 4;  // every wave of a block gets the same number of tiles
+    if (tpb < 4) tpb = 4;
+    p.tiles_per_block = (int)tpb;
+    p.slabs = (int)((ntiles + tpb - 1) / tpb);
+    return p;
+}
+
+int launch_scan(mmiss_index* ix, hipStream_t st, const ScanArgs& a, const ScanPlan& p) {
+    const double flops = 2.0 * a.Q * (double)a.N * a.D;
+    const double bytes = (double)a.N * a.D * ix->elt;
+    MM_PROF(ix->dtype == MMISS_F16 ? "scan_topk_f16" : "scan_topk_f32", st, flops, bytes);
+    if (ix->dtype == MMISS_F16) {
+        if (p.nqt == 1) return launch_scan_t<_Float16, 1, 64>(st, a, p.slabs, p.qtiles, p.lds);
+        if (p.nqt == 2) return launch_scan_t<_Float16, 2, 32>(st, a, p.slabs, p.qtiles, p.lds);
+        return launch_scan_t<_Float16, 4, 32>(st, a, p.slabs, p.qtiles, p.lds);
+    }
+    if (p.nqt == 1) return launch_scan_t<float, 1, 64>(st, a, p.slabs, p.qtiles, p.lds);
+    if (p.nqt == 2) return launch_scan_t<float, 2, 32>(st, a, p.slabs, p.qtiles, p.lds);
+    return launch_scan_t<float, 4, 32>(st, a, p.slabs, p.qtiles, p.lds);
+}
+
+}  // namespace
+
+// ================================================================================================ lifecycle
+extern "C" int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device, int64_t capacity_hint,
+                                  mmiss_index** out) {
+    if (!out) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_create: null out");
+    if (dim <= 0 || dim % 128 || dim > 4096) MM_FAIL(MMISS_ERR_UNSUPPORTED, "index dim %d: need a multiple of 128, <= 4096", dim);
+    if (storage_dtype != MMISS_F32 && storage_dtype != MMISS_F16) MM_FAIL(MMISS_ERR_ARG, "unknown storage dtype %d", storage_dtype);
+    MM_TRY(mmiss_use_device(device));
+    mmiss_index* ix = new (std::nothrow) mmiss_index();
+    if (!ix) MM_FAIL(MMISS_ERR_NOMEM, "out of host memory");
+    ix->dim = dim; ix->dtype = storage_dtype; ix->device = device; ix->elt = storage_dtype == MMISS_F16 ? 2 : 4;
+    if (hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ix;
+        MM_FAIL(MMISS_ERR_HIP, "hipStreamCreate failed");
+    }
+    if (capacity_hint > 0) {
+        int rc = index_reserve(ix, capacity_hint, ix->own_stream);
+        if (rc != MMISS_OK) { (void)hipStreamDestroy(ix->own_stream); delete ix; return rc; }
+    }
+    *out = ix;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_destroy(mmiss_index* ix) {
+    if (!ix) return MMISS_OK;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+    delete ix;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_set_stream(mmiss_index* ix, void* hip_stream) {
+    if (!ix) MM_FAIL(MMISS_ERR_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
+    ix->has_user_stream = hip_stream != nullptr;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_count(mmiss_index* ix, int64_t* count) {
+    if (!ix || !count) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_count: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    *count = ix->count;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_clear(mmiss_index* ix) {
+    if (!ix) MM_FAIL(MMISS_ERR_ARG, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->count = 0;
+    ix->labels_h.clear();
+    return MMISS_OK;
+}
+
+// ================================================================================================ mutation
+extern "C" int mmiss_index_add(mmiss_index* ix, const float* vecs, const int64_t* labels, int64_t n) {
+    if (!ix || (n > 0 && (!vecs || !labels))) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_add: null argument");
+    if (n < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_add: n = %lld", (long long)n);
+    if (n == 0) return MMISS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_TRY(mmiss_use_device(ix->device));
+    hipStream_t st = ix->stream();
+    std::vector<int64_t> lab;
+    MM_TRY(fetch_i64(labels, n, lab));
+    int64_t prev = ix->labels_h.empty() ? INT64_MIN : ix->labels_h.back();
+    for (int64_t i = 0; i < n; ++i) {
+        if (lab[i] < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_add: negative label %lld", (long long)lab[i]);
+        if (lab[i] <= prev)
+            MM_FAIL(MMISS_ERR_ARG, "mmiss_index_add: labels must be strictly increasing (label %lld after %lld)",
+                    (long long)lab[i], (long long)prev);
+        prev = lab[i];
+    }
+    if (ix->count + n >= (int64_t)INT32_MAX - 64) MM_FAIL(MMISS_ERR_UNSUPPORTED, "index shard limited to 2^31 rows");
+    MM_TRY(index_reserve(ix, ix->count + n, st));
+    const int D = ix->dim;
+    const bool in_dev = mmiss_is_device_ptr(vecs);
+    const int64_t chunk = 1 << 16;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t nr = std::min(chunk, n - r0);
+        const float* src = vecs + r0 * D;
+        if (!in_dev) {
+            MM_TRY(ix->stage.ensure((size_t)chunk * D * 4));
+            MM_HIP(hipMemcpyAsync(ix->stage.p, src, (size_t)nr * D * 4, hipMemcpyHostToDevice, st));
+            src = ix->stage.as<float>();
+        }
+        MM_TRY(launch_normalize(ix, src, ix->rows.as<char>() + (size_t)(ix->count + r0) * D * ix->elt, nr, st));
+        if (!in_dev) MM_HIP(hipStreamSynchronize(st));
+    }
+    MM_HIP(hipMemcpyAsync(ix->labels_d.as<int64_t>() + ix->count, lab.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    MM_HIP(hipStreamSynchronize(st));
+    ix->labels_h.insert(ix->labels_h.end(), lab.begin(), lab.end());
+    ix->count += n;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_update(mmiss_index* ix, const int64_t* labels, const float* vecs, int64_t n) {
+    if (!ix || (n > 0 && (!vecs || !labels))) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_update: null argument");
+    if (n <= 0) return n == 0 ? MMISS_OK : MMISS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_TRY(mmiss_use_device(ix->device));
+    hipStream_t st = ix->stream();
+    std::vector<int64_t> lab;
+    MM_TRY(fetch_i64(labels, n, lab));
+    std::vector<int64_t> rows((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        rows[i] = find_row(ix, lab[i]);
+        if (rows[i] < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_update: label %lld not in the index", (long long)lab[i]);
+    }
+    const int D = ix->dim;
+    const float* src = vecs;
+    if (!mmiss_is_device_ptr(vecs)) {
+        MM_TRY(ix->stage.ensure((size_t)n * D * 4));
+        MM_HIP(hipMemcpyAsync(ix->stage.p, vecs, (size_t)n * D * 4, hipMemcpyHostToDevice, st));
+        src = ix->stage.as<float>();
+    }
+    for (int64_t i = 0; i < n; ++i)
+        MM_TRY(launch_normalize(ix, src + i * D, ix->rows.as<char>() + (size_t)rows[i] * D * ix->elt, 1, st));
+    MM_HIP(hipStreamSynchronize(st));
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_remove(mmiss_index* ix, const int64_t* labels, int64_t n, int64_t* removed) {
+    if (!ix || (n > 0 && !labels)) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_remove: null argument");
+    if (removed) *removed = 0;
+    if (n <= 0) return n == 0 ? MMISS_OK : MMISS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_TRY(mmiss_use_device(ix->device));
+    hipStream_t st = ix->stream();
+    std::vector<int64_t> lab;
+    MM_TRY(fetch_i64(labels, n, lab));
+    std::vector<char> drop((size_t)ix->count, 0);
+    int64_t ndrop = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = find_row(ix, lab[i]);
+        if (r >= 0 && !drop[r]) { drop[r] = 1; ++ndrop; }
+    }
+    if (removed) *removed = ndrop;
+    if (ndrop == 0) return MMISS_OK;
+    const int64_t keep = ix->count - ndrop;
+    std::vector<int64_t> map((size_t)keep), nl((size_t)keep);
+    for (int64_t r = 0, o = 0; r < ix->count; ++r)
+        if (!drop[r]) { map[o] = r; nl[o] = ix->labels_h[r]; ++o; }
+    if (keep > 0) {
+        // stable compaction into fresh buffers (row order == label order is the tie-break contract)
+        DevBuf nr, nlab;
+        MM_TRY(nr.alloc((size_t)ix->capacity * ix->dim * ix->elt));
+        MM_TRY(nlab.alloc((size_t)ix->capacity * 8));
+        MM_TRY(ix->map.ensure((size_t)keep * 8));
+        MM_HIP(hipMemcpyAsync(ix->map.p, map.data(), (size_t)keep * 8, hipMemcpyHostToDevice, st));
+        const int grid = (int)std::min<int64_t>(4096, (keep * ix->dim + 255) / 256);
+        if (ix->dtype == MMISS_F16)
+            hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.as<_Float16>(),
+                               ix->map.as<int64_t>(), nr.as<_Float16>(), keep, ix->dim);
+        else
+            hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.as<float>(),
+                               ix->map.as<int64_t>(), nr.as<float>(), keep, ix->dim);
+        MM_HIP(hipGetLastError());
+        MM_HIP(hipMemcpyAsync(nlab.p, nl.data(), (size_t)keep * 8, hipMemcpyHostToDevice, st));
+        MM_HIP(hipStreamSynchronize(st));
+        std::swap(ix->rows.p, nr.p); std::swap(ix->rows.bytes, nr.bytes);
+        std::swap(ix->labels_d.p, nlab.p); std::swap(ix->labels_d.bytes, nlab.bytes);
+    }
+    ix->labels_h.swap(nl);
+    ix->count = keep;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_get(mmiss_index* ix, const int64_t* labels, int64_t n, float* out) {
+    if (!ix || (n > 0 && (!labels || !out))) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_get: null argument");
+    if (n <= 0) return n == 0 ? MMISS_OK : MMISS_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_TRY(mmiss_use_device(ix->device));
+    hipStream_t st = ix->stream();
+    std::vector<int64_t> lab;
+    MM_TRY(fetch_i64(labels, n, lab));
+    std::vector<int64_t> map((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        map[i] = find_row(ix, lab[i]);
+        if (map[i] < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_get: label %lld not in the index", (long long)lab[i]);
+    }
+    MM_TRY(ix->map.ensure((size_t)n * 8));
+    MM_HIP(hipMemcpyAsync(ix->map.p, map.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    const bool out_dev = mmiss_is_device_ptr(out);
+    float* dst = out;
+    if (!out_dev) { MM_TRY(ix->stage.ensure((size_t)n * ix->dim * 4)); dst = ix->stage.as<float>(); }
+    const int grid = (int)std::min<int64_t>(4096, (n * ix->dim + 255) / 256);
+    if (ix->dtype == MMISS_F16)
+        hipLaunchKernelGGL(gather_rows_f32_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.as<_Float16>(),
+                           ix->map.as<int64_t>(), dst, n, ix->dim);
+    else
+        hipLaunchKernelGGL(gather_rows_f32_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.as<float>(),
+                           ix->map.as<int64_t>(), dst, n, ix->dim);
+    MM_HIP(hipGetLastError());
+    if (!out_dev) MM_HIP(hipMemcpyAsync(out, dst, (size_t)n * ix->dim * 4, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_labels(mmiss_index* ix, int64_t* out, int64_t cap) {
+    if (!ix || (!out && cap > 0)) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_labels: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    const int64_t n = std::min<int64_t>(cap, ix->count);
+    if (n > 0) memcpy(out, ix->labels_h.data(), (size_t)n * 8);
+    return MMISS_OK;
+}
+
+// ================================================================================================ query
+extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t Q, int32_t k, int64_t* out_labels,
+                                 float* out_dist, int32_t* out_count) {
+    if (!ix || !queries || !out_labels || !out_dist) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query: null argument");
+    if (Q < 0 || k <= 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query: Q=%d k=%d", Q, k);
+    if (Q == 0) return MMISS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_TRY(mmiss_use_device(ix->device));
+    hipStream_t st = ix->stream();
+    const int D = ix->dim;
+    const int64_t N = ix->count;
+    const bool out_dev = mmiss_is_device_ptr(out_labels);
+    if (out_dev != mmiss_is_device_ptr(out_dist) || (out_count && out_dev != mmiss_is_device_ptr(out_count)))
+        MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query: output pointers must be all host or all device");
+
+    // outputs on device
+    int64_t* d_lab = out_labels; float* d_dist = out_dist; int32_t* d_cnt = out_count;
+    if (!out_dev) {
+        MM_TRY(ix->out_l.ensure((size_t)Q * k * 8));
+        MM_TRY(ix->out_d.ensure((size_t)Q * k * 4));
+        d_lab = ix->out_l.as<int64_t>(); d_dist = ix->out_d.as<float>();
+    }
+    MM_TRY(ix->out_c.ensure((size_t)Q * 4));
+    if (!out_dev || !out_count) d_cnt = ix->out_c.as<int32_t>();
+
+    // effective k: never more than the rows there are
+    int kp, pages;
+    const int64_t want = std::min<int64_t>(k, N);
+    if (want <= 10) { kp = 16; pages = 1; }
+    else if (want <= 24) { kp = 32; pages = 1; }
+    else {
+        kp = 32;
+        pages = (int)((std::min<int64_t>(want + 8, N) + 31) / 32);
+    }
+    const int ncand = kp * pages;
+    if (ncand > 2048) MM_FAIL(MMISS_ERR_UNSUPPORTED, "mmiss_index_query: k = %d too large (max 2040)", k);
+
+    // queries -> device, canonical normalisation
+    const int Qpad = (int)round_up(Q, 64);
+    const float* qsrc = queries;
+    if (!mmiss_is_device_ptr(queries)) {
+        MM_TRY(ix->qstage.ensure((size_t)Q * D * 4));
+        MM_HIP(hipMemcpyAsync(ix->qstage.p, queries, (size_t)Q * D * 4, hipMemcpyHostToDevice, st));
+        qsrc = ix->qstage.as<float>();
+    }
+    MM_TRY(ix->qn.ensure((size_t)Qpad * D * 4));
+    MM_TRY(ix->qs.ensure((size_t)Qpad * D * ix->elt));
+    {
+        MM_PROF("prep_queries", st, 4.0 * Q * D, (double)Q * D * (8 + ix->elt));
+        const int grid = (Qpad + 3) / 4;
+        if (ix->dtype == MMISS_F16)
+            hipLaunchKernelGGL(prep_queries_kernel<_Float16>, dim3(grid), dim3(256), 0, st, qsrc, ix->qn.as<float>(),
+                               ix->qs.as<_Float16>(), Q, Qpad, D);
+        else
+            hipLaunchKernelGGL(prep_queries_kernel<float>, dim3(grid), dim3(256), 0, st, qsrc, ix->qn.as<float>(),
+                               ix->qs.as<float>(), Q, Qpad, D);
+        MM_HIP(hipGetLastError());
+    }
+
+    MM_TRY(ix->cand.ensure((size_t)Q * ncand * 4));
+    if (N == 0) {
+        MM_HIP(hipMemsetAsync(ix->cand.p, 0xff, (size_t)Q * ncand * 4, st));  // all -1
+    } else {
+        const ScanPlan p = plan_scan(D, ix->elt, Q, kp, N);
+        MM_TRY(ix->lists_s.ensure((size_t)p.slabs * Q * kp * 4));
+        MM_TRY(ix->lists_r.ensure((size_t)p.slabs * Q * kp * 4));
+        const bool paging = pages > 1;
+        if (paging) {
+            MM_TRY(ix->cur_s.ensure((size_t)Q * 4));
+            MM_TRY(ix->cur_r.ensure((size_t)Q * 4));
+            std::vector<float> inf((size_t)Q, INFINITY);
+            std::vector<int32_t> neg((size_t)Q, -1);
+            MM_HIP(hipMemcpyAsync(ix->cur_s.p, inf.data(), (size_t)Q * 4, hipMemcpyHostToDevice, st));
+            MM_HIP(hipMemcpyAsync(ix->cur_r.p, neg.data(), (size_t)Q * 4, hipMemcpyHostToDevice, st));
+            MM_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
+        }
+        for (int page = 0; page < pages; ++page) {
+            ScanArgs a{};
+            a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = ix->qs.p; a.Q = Q;
+            a.cur_s = paging ? ix->cur_s.as<float>() : nullptr;
+            a.cur_r = paging ? ix->cur_r.as<int32_t>() : nullptr;
+            a.kp = kp; a.tiles_per_block = p.tiles_per_block;
+            a.out_s = ix->lists_s.as<float>(); a.out_r = ix->lists_r.as<int32_t>();
+            MM_TRY(launch_scan(ix, st, a, p));
+            MergeArgs m{};
+            m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
+            m.L = p.slabs; m.Q = Q; m.kp = kp;
+            m.cand = ix->cand.as<int32_t>(); m.cand_stride = ncand; m.page_off = page * kp;
+            m.cur_s = paging ? ix->cur_s.as<float>() : nullptr;
+            m.cur_r = paging ? ix->cur_r.as<int32_t>() : nullptr;
+            {
+                MM_PROF("merge_lists", st, 0.0, (double)p.slabs * Q * kp * 8);
+                hipLaunchKernelGGL(merge_lists_kernel, dim3(Q), dim3(256), 0, st, m);
+                MM_HIP(hipGetLastError());
+            }
+        }
+    }
+    {
+        RerankArgs r{};
+        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand.as<int32_t>();
+        r.cand_stride = ncand; r.ncand = ncand; r.labels = ix->labels_d.as<int64_t>(); r.k = k;
+        r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
+        int npow = 1;
+        while (npow < ncand) npow <<= 1;
+        const int lds = npow * 12 + 16;
+        MM_PROF("rerank", st, 2.0 * Q * ncand * D, (double)Q * ncand * D * ix->elt);
+        if (ix->dtype == MMISS_F16)
+            hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(Q), dim3(256), lds, st, r);
+        else
+            hipLaunchKernelGGL(rerank_kernel<float>, dim3(Q), dim3(256), lds, st, r);
+        MM_HIP(hipGetLastError());
+    }
+    if (!out_dev) {
+        MM_HIP(hipMemcpyAsync(out_labels, d_lab, (size_t)Q * k * 8, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)Q * k * 4, hipMemcpyDeviceToHost, st));
+        if (out_count) MM_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipStreamSynchronize(st));
+    } else if (!ix->has_user_stream) {
+        MM_HIP(hipStreamSynchronize(st));
+    }
+    return MMISS_OK;
+}
+
+// ================================================================================================ persistence
+namespace {
+struct IdxHeader {
+    char magic[8];
+    int32_t version, dim, dtype, reserved;
+    int64_t count;
+};
+}  // namespace
+
+extern "C" int mmiss_index_save(mmiss_index* ix, const char* path) {
+    if (!ix || !path) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_save: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_TRY(mmiss_use_device(ix->device));
+    MM_HIP(hipStreamSynchronize(ix->stream()));
+    FILE* f = fopen(path, "wb");
+    if (!f) MM_FAIL(MMISS_ERR_IO, "cannot open %s for writing", path);
+    IdxHeader h{};
+    memcpy(h.magic, "MMISSIDX", 8);
+    h.version = 1; h.dim = ix->dim; h.dtype = ix->dtype; h.count = ix->count;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    if (ok && ix->count) ok = fwrite(ix->labels_h.data(), 8, (size_t)ix->count, f) == (size_t)ix->count;
+    const size_t row_bytes = (size_t)ix->dim * ix->elt;
+    const int64_t chunk = std::max<int64_t>(1, (64 << 20) / (int64_t)row_bytes);
+    std::vector<char> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(ix->count, 1)) * row_bytes);
+    for (int64_t r0 = 0; ok && r0 < ix->count; r0 += chunk) {
+        const int64_t nr = std::min(chunk, ix->count - r0);
+        if (hipMemcpy(buf.data(), ix->rows.as<char>() + (size_t)r0 * row_bytes, (size_t)nr * row_bytes,
+                      hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = fwrite(buf.data(), row_bytes, (size_t)nr, f) == (size_t)nr;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) MM_FAIL(MMISS_ERR_IO, "write to %s failed", path);
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_load(mmiss_index* ix, const char* path) {
+    if (!ix || !path) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_load: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_TRY(mmiss_use_device(ix->device));
+    hipStream_t st = ix->stream();
+    FILE* f = fopen(path, "rb");
+    if (!f) MM_FAIL(MMISS_ERR_IO, "cannot open %s", path);
+    IdxHeader h{};
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "MMISSIDX", 8) != 0 || h.version != 1) {
+        fclose(f);
+        MM_FAIL(MMISS_ERR_IO, "%s is not an mmiss index file", path);
+    }
+    if (h.dim != ix->dim || h.dtype != ix->dtype || h.count < 0) {
+        fclose(f);
+        MM_FAIL(MMISS_ERR_ARG, "%s holds dim %d dtype %d; this index is dim %d dtype %d", path, h.dim, h.dtype, ix->dim,
+                ix->dtype);
+    }
+    std::vector<int64_t> lab((size_t)h.count);
+    bool ok = h.count == 0 || fread(lab.data(), 8, (size_t)h.count, f) == (size_t)h.count;
+    for (int64_t i = 1; ok && i < h.count; ++i) ok = lab[i] > lab[i - 1];
+    int rc = MMISS_OK;
+    if (ok) rc = index_reserve(ix, h.count, st);
+    const size_t row_bytes = (size_t)ix->dim * ix->elt;
+    const int64_t chunk = std::max<int64_t>(1, (64 << 20) / (int64_t)row_bytes);
+    std::vector<char> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(h.count, 1)) * row_bytes);
+    for (int64_t r0 = 0; ok && rc == MMISS_OK && r0 < h.count; r0 += chunk) {
+        const int64_t nr = std::min(chunk, h.count - r0);
+        ok = fread(buf.data(), row_bytes, (size_t)nr, f) == (size_t)nr;
+        if (ok && hipMemcpy(ix->rows.as<char>() + (size_t)r0 * row_bytes, buf.data(), (size_t)nr * row_bytes,
+                            hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    }
+    fclose(f);
+    if (rc != MMISS_OK) return rc;
+    if (!ok) MM_FAIL(MMISS_ERR_IO, "%s is truncated or corrupt", path);
+    if (h.count) MM_HIP(hipMemcpy(ix->labels_d.p, lab.data(), (size_t)h.count * 8, hipMemcpyHostToDevice));
+    ix->labels_h.swap(lab);
+    ix->count = h.count;
+    return MMISS_OK;
+}
+
+// ================================================================================================ glue kernels
+extern "C" int mmiss_blend(int device, void* hip_stream, const float* img, const float* txt, double w, int32_t Q,
+                           int32_t dim, float* out) {
+    if (!img || !txt || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_blend: null argument");
+    if (Q < 0 || dim <= 0 || dim % 64) MM_FAIL(MMISS_ERR_ARG, "mmiss_blend: Q=%d dim=%d (dim must be a multiple of 64)", Q, dim);
+    if (Q == 0) return MMISS_OK;
+    MM_TRY(mmiss_use_device(device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const size_t bytes = (size_t)Q * dim * 4;
+    DevBuf bi, bt, bo;
+    const float *di = img, *dt = txt;
+    float* dout = out;
+    if (!mmiss_is_device_ptr(img)) { MM_TRY(bi.alloc(bytes)); MM_HIP(hipMemcpyAsync(bi.p, img, bytes, hipMemcpyHostToDevice, st)); di = bi.as<float>(); }
+    if (!mmiss_is_device_ptr(txt)) { MM_TRY(bt.alloc(bytes)); MM_HIP(hipMemcpyAsync(bt.p, txt, bytes, hipMemcpyHostToDevice, st)); dt = bt.as<float>(); }
+    const bool out_dev = mmiss_is_device_ptr(out);
+    if (!out_dev) { MM_TRY(bo.alloc(bytes)); dout = bo.as<float>(); }
+    {
+        MM_PROF("blend", st, 12.0 * Q * dim, 3.0 * bytes);
+        hipLaunchKernelGGL(blend_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, di, dt, (float)w, (float)(1.0 - w), Q, dim, dout);
+        MM_HIP(hipGetLastError());
+    }
+    if (!out_dev) MM_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
+    if (!out_dev || bi.p || bt.p || !hip_stream) MM_HIP(hipStreamSynchronize(st));
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_merge_topk(int device, void* hip_stream, const float* dist, const int64_t* labels, int32_t S,
+                                int32_t Q, int32_t k, float* out_dist, int64_t* out_labels, int32_t* out_count) {
+    if (!dist || !labels || !out_dist || !out_labels) MM_FAIL(MMISS_ERR_ARG, "mmiss_merge_topk: null argument");
+    if (S <= 0 || Q < 0 || k <= 0 || (int64_t)S * k > 4096)
+        MM_FAIL(MMISS_ERR_ARG, "mmiss_merge_topk: S=%d Q=%d k=%d (S*k must be <= 4096)", S, Q, k);
+    if (Q == 0) return MMISS_OK;
+    MM_TRY(mmiss_use_device(device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const size_t n_in = (size_t)S * Q * k, n_out = (size_t)Q * k;
+    DevBuf bd, bl, bod, bol, boc;
+    const float* dd = dist; const int64_t* dl = labels;
+    float* dod = out_dist; int64_t* dol = out_labels; int32_t* doc = out_count;
+    if (!mmiss_is_device_ptr(dist)) { MM_TRY(bd.alloc(n_in * 4)); MM_HIP(hipMemcpyAsync(bd.p, dist, n_in * 4, hipMemcpyHostToDevice, st)); dd = bd.as<float>(); }
+    if (!mmiss_is_device_ptr(labels)) { MM_TRY(bl.alloc(n_in * 8)); MM_HIP(hipMemcpyAsync(bl.p, labels, n_in * 8, hipMemcpyHostToDevice, st)); dl = bl.as<int64_t>(); }
+    const bool out_dev = mmiss_is_device_ptr(out_dist);
+    if (!out_dev) {
+        MM_TRY(bod.alloc(n_out * 4)); MM_TRY(bol.alloc(n_out * 8)); MM_TRY(boc.alloc((size_t)Q * 4));
+        dod = bod.as<float>(); dol = bol.as<int64_t>(); doc = boc.as<int32_t>();
+    }
+    int npow = 1;
+    while (npow < S * k) npow <<= 1;
+    {
+        MM_PROF("shard_merge", st, 0.0, (double)n_in * 12);
+        hipLaunchKernelGGL(shard_merge_kernel, dim3(Q), dim3(256), npow * 12 + 16, st, dd, dl, S, Q, k, dod, dol, doc);
+        MM_HIP(hipGetLastError());
+    }
+    if (!out_dev) {
+        MM_HIP(hipMemcpyAsync(out_dist, dod, n_out * 4, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipMemcpyAsync(out_labels, dol, n_out * 8, hipMemcpyDeviceToHost, st));
+        if (out_count) MM_HIP(hipMemcpyAsync(out_count, doc, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (!out_dev || bd.p || bl.p || !hip_stream) MM_HIP(hipStreamSynchronize(st));
+    return MMISS_OK;
+}

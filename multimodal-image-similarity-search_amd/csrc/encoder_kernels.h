@@ -1,0 +1,410 @@
+// encoder_kernels.h — the non-GEMM kernels of the CLIP towers (K1 prologue, K2, K4, K8, K9 of
+// SURVEY.md §2.2). Each kernel cites the HF arithmetic it restates.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K1 prologue: patchify.  pixels f32 [B,3,S,S] -> patches bf16 [B*G*G, Kp], k = c*P*P + ky*P + kx
+// (the flatten order of nn.Conv2d's weight [d,3,P,P], HF:modeling_clip.py:148-154,209-211), zero
+// padded from 3*P*P to Kp. One thread produces 8 consecutive k (one 16-byte store).
+// SRC_U8: pixels are uint8 [B,S,S,3] HWC and the CLIP rescale+normalise
+// ((x/255 - mean)/std, HF:image_processing_clip.py:23-34) is fused in.
+// ------------------------------------------------------------------------------------------------
+template <bool SRC_U8>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ pixels, uint16_t* __restrict__ out,
+                                                     int B, int S, int P, int Kp) {
+    const int G = S / P;
+    const int PP = P * P;
+    const int Kreal = 3 * PP;
+    const int kgroups = Kp >> 3;
+    const int64_t total = (int64_t)B * G * G * kgroups;
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    const float istd[3] = {1.0f / 0.26862954f, 1.0f / 0.26130258f, 1.0f / 0.27577711f};
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int kg = (int)(idx % kgroups);
+        const int64_t m = idx / kgroups;
+        const int b = (int)(m / (G * G));
+        const int pr = (int)(m - (int64_t)b * G * G);
+        const int py = pr / G, px = pr - py * G;
+        const int k0 = kg << 3;
+        float v[8];
+        if (!SRC_U8 && (P & 7) == 0 && k0 < Kreal) {
+            // 8 consecutive kx of one (c, ky): two float4 loads
+            const int c = k0 / PP, rem = k0 - c * PP, ky = rem / P, kx = rem - ky * P;
+            const float* src = reinterpret_cast<const float*>(pixels) +
+                               (((size_t)b * 3 + c) * S + (size_t)py * P + ky) * S + (size_t)px * P + kx;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(src + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+            v[4] = d[0]; v[5] = d[1]; v[6] = d[2]; v[7] = d[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                float x = 0.f;
+                if (k < Kreal) {
+                    const int c = k / PP, rem = k - c * PP, ky = rem / P, kx = rem - ky * P;
+                    const size_t y = (size_t)py * P + ky, xx = (size_t)px * P + kx;
+                    if (SRC_U8) {
+                        const uint8_t u = reinterpret_cast<const uint8_t*>(pixels)[(((size_t)b * S + y) * S + xx) * 3 + c];
+                        // same op order as the HF processor: rescale (x * 1/255) then (x - mean) / std
+                        x = ((float)u * (1.0f / 255.0f) - mean[c]) * istd[c];
+                    } else {
+                        x = reinterpret_cast<const float*>(pixels)[(((size_t)b * 3 + c) * S + y) * S + xx];
+                    }
+                }
+                v[e] = x;
+            }
+        }
+        u32x4 pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        pk[2] = pack_bf16x2(v[4], v[5]);
+        pk[3] = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<u32x4*>(out + (size_t)m * Kp + k0) = pk;
+    }
+}
+
+// CLS rows: x[b*T + 0][:] = class_embedding + position_embedding[0]   (HF:modeling_clip.py:213-216)
+__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                int B, int T, int d) {
+    const int64_t total = (int64_t)B * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / d), n = (int)(i - (int64_t)b * d);
+        x[(size_t)b * T * d + n] = cls[n] + pos[n];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9: text embeddings.  x[b*T+t][:] = token_embedding[ids[b,t]] + position_embedding[t]
+// (HF:modeling_clip.py:226-256). Also finds the pooled position per row: first id == eos_id, or
+// argmax(ids) when eos_id == 2 (legacy checkpoints) — HF:modeling_clip.py:561-581.
+// One block per (b); threads stride over t*d.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ tok,
+                                                         const float* __restrict__ pos, float* __restrict__ x,
+                                                         int32_t* __restrict__ pool_row, int T, int d, int vocab,
+                                                         int eos_id) {
+    const int b = blockIdx.x;
+    const int32_t* row = ids + (size_t)b * T;
+    if (threadIdx.x == 0) {
+        int pos_eos = 0;
+        if (eos_id == 2) {
+            int best = row[0];
+            for (int t = 1; t < T; ++t)
+                if (row[t] > best) { best = row[t]; pos_eos = t; }
+        } else {
+            // (ids == eos).int().argmax(): first match, 0 when there is none
+            for (int t = 0; t < T; ++t)
+                if (row[t] == eos_id) { pos_eos = t; break; }
+        }
+        pool_row[b] = b * T + pos_eos;
+    }
+    const int dv = d >> 2;
+    for (int i = threadIdx.x; i < T * dv; i += blockDim.x) {
+        const int t = i / dv, c = (i - t * dv) << 2;
+        int id = row[t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 e = *reinterpret_cast<const f32x4*>(tok + (size_t)id * d + c);
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (size_t)t * d + c);
+        *reinterpret_cast<f32x4*>(x + ((size_t)b * T + t) * d + c) = e + p;
+    }
+}
+
+// vision pooled row = token 0 of every image (HF:modeling_clip.py:650-651)
+__global__ void vision_pool_rows_kernel(int32_t* pool_row, int B, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) pool_row[i] = i * T;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: LayerNorm (eps inside the sqrt, affine; fp32 statistics) — F.layer_norm as used by
+// pre_layrnorm / layer_norm1 / layer_norm2 / post_layernorm / final_layer_norm
+// (HF:modeling_clip.py:358-360,605-607,504). One wave per row, the row held in registers
+// (d <= 1024), two-pass mean / variance. rowmap (optional) gathers input rows: out row r reads
+// x row rowmap[r]  (K8's pooling).
+// ------------------------------------------------------------------------------------------------
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ out,
+                                                        const int32_t* __restrict__ rowmap, int M, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const size_t in_row = rowmap ? (size_t)rowmap[r] : (size_t)r;
+    const float* xr = x + in_row * d;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (c < d) ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            if constexpr (OUT_BF16) {
+                u32x2 pk;
+                pk[0] = pack_bf16x2(y[0], y[1]);
+                pk[1] = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(out) + (size_t)r * d + c) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)r * d + c) = y;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: multi-head attention core, head_dim 64:  ctx = softmax(Q K^T * 64^-0.5 (+causal mask)) V
+// (HF:modeling_clip.py:259-277,280-335; text mask :543-548). Softmax statistics in fp32 as HF does.
+//
+// One workgroup per (image/text b, head h), 4 waves, each wave owns 16-query tiles.
+// Per wave and query tile everything stays in registers:
+//   S^T = K Q^T   (MFMA A = K tile from LDS, B = Q fragment from global)  -> lane holds, for ITS query
+//                 (lane & 15), keys 4*(lane>>4)+reg of every 16-key tile: the softmax reduction over
+//                 keys is in-lane plus two xor-shuffles (16, 32).
+//   O^T = V^T P^T (A = V^T via ds_read_b64_tr_b16 from a row-major V image, B = P^T straight from the
+//                 S^T accumulator registers: no LDS round trip, no lane movement — guide §3
+//                 "An accumulator tile as the next MFMA's operand", with the k order of both
+//                 operands permuted the same way).
+// NKP = padded key count / 32.
+// ------------------------------------------------------------------------------------------------
+#define ATT_VSTRIDE 144  // bytes per V row in LDS (128 + 16 pad: spreads the tr-read's 8 rows over banks)
+
+template <int NKP, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
+                                                        int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKP * 32;
+    char* sK = smem;             // [TP][128 B], 16-B chunks XOR-swizzled by (row & 7)
+    char* sV = smem + TP * 128;  // [TP][144 B] row-major
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const int dmodel = H * 64, ld = 3 * dmodel;
+    const uint16_t* base = qkv + (size_t)b * T * ld + h * 64;
+
+    for (int idx = tid; idx < TP * 8; idx += 256) {
+        const int row = idx >> 3, c = idx & 7;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (row < T) {
+            kv = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + dmodel + c * 8);
+            vv = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + 2 * dmodel + c * 8);
+        }
+        *reinterpret_cast<u32x4*>(sK + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
+        *reinterpret_cast<u32x4*>(sV + row * ATT_VSTRIDE + (c << 4)) = vv;
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nqt = (T + 15) >> 4;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q = qt * 16 + fr;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (q < T) raw = *reinterpret_cast<const u32x4*>(base + (size_t)q * ld + s * 32 + fg * 8);
+            qf[s] = __builtin_bit_cast(bf16x8, raw);
+        }
+        f32x4 sacc[2 * NKP];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKP; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const int krow = kt * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int chunk = 4 * s + fg;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((chunk ^ (krow & 7)) << 4));
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + 4 * fg + r;
+                const bool ok = (key < T) && (!CAUSAL || key <= q);
+                a[r] = ok ? a[r] * 0.125f : -INFINITY;
+                mx = fmaxf(mx, a[r]);
+            }
+            sacc[kt] = a;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2 * NKP; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pexp = __expf(sacc[kt][r] - mx);
+                sacc[kt][r] = pexp;
+                l += pexp;
+            }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int tq = fr >> 2, tp = fr & 3;  // tr-read address role inside the 16-lane group
+#pragma unroll
+        for (int ks = 0; ks < NKP; ++ks) {
+            // B fragment: element j<4 = key 32ks + 4fg + j, j>=4 = key 32ks + 16 + 4fg + (j-4)
+            u32x4 praw;
+            praw[0] = pack_bf16x2(sacc[2 * ks][0], sacc[2 * ks][1]);
+            praw[1] = pack_bf16x2(sacc[2 * ks][2], sacc[2 * ks][3]);
+            praw[2] = pack_bf16x2(sacc[2 * ks + 1][0], sacc[2 * ks + 1][1]);
+            praw[3] = pack_bf16x2(sacc[2 * ks + 1][2], sacc[2 * ks + 1][3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* a0 = sV + (32 * ks + 4 * fg + tq) * ATT_VSTRIDE + (dt * 16 + 4 * tp) * 2;
+                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(a0));
+                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (__attribute__((address_space(3))) bf16x4*)(a0 + 16 * ATT_VSTRIDE));
+                bf16x8 vf;
+                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+        const float inv = 1.0f / l;
+        if (q < T) {
+            uint16_t* orow = ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                u32x2 pk;
+                pk[0] = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+                pk[1] = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+                *reinterpret_cast<u32x2*>(orow + dt * 16) = pk;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8 tail / a7: out[r] = y[r] / ||y[r]||_2, fp32, no epsilon (backend/app/utils.py:78,98).
+// One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
+                                                          int D, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    const float* yr = y + (size_t)r * ldy;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += yr[c] * yr[c];
+    const float nrm = sqrtf(wave_sum(s));
+    for (int c = lane; c < D; c += 64) out[(size_t)r * D + c] = yr[c] / nrm;
+}
+
+// f32 -> bf16 conversion (weight upload)
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        bf16_t v = (bf16_t)src[i];
+        dst[i] = __builtin_bit_cast(uint16_t, v);
+    }
+}
+// bf16 -> f32 widening (debug taps)
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = bf16_bits_to_f32(src[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static int launch_layernorm(hipStream_t st, const float* x, const float* g, const float* b, void* out, bool out_bf16,
+                            const int32_t* rowmap, int M, int d, float eps) {
+    if (d % 4 || d > 1024 || d <= 0) MM_FAIL(MMISS_ERR_UNSUPPORTED, "layernorm: d=%d (need d%%4==0, d<=1024)", d);
+    if (M <= 0) return MMISS_OK;
+    MM_PROF("layernorm", st, 8.0 * M * d, (double)M * d * (4 + (out_bf16 ? 2 : 4)));
+    const int grid = (M + 3) / 4;
+    if (out_bf16)
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3(grid), dim3(256), 0, st, x, g, b, out, rowmap, M, d, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3(grid), dim3(256), 0, st, x, g, b, out, rowmap, M, d, eps);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+static int launch_im2col(hipStream_t st, const void* pixels, bool src_u8, void* out, int B, int S, int P, int Kp) {
+    if (P <= 0 || S % P || Kp % 8 || Kp < 3 * P * P) MM_FAIL(MMISS_ERR_ARG, "im2col: S=%d P=%d Kp=%d", S, P, Kp);
+    if (B <= 0) return MMISS_OK;
+    const int G = S / P;
+    const int64_t total = (int64_t)B * G * G * (Kp / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    MM_PROF("im2col", st, 0.0, (double)B * 3 * S * S * (src_u8 ? 1 : 4) + (double)B * G * G * Kp * 2);
+    if (src_u8)
+        hipLaunchKernelGGL(im2col_kernel<true>, dim3(grid), dim3(256), 0, st, pixels, (uint16_t*)out, B, S, P, Kp);
+    else
+        hipLaunchKernelGGL(im2col_kernel<false>, dim3(grid), dim3(256), 0, st, pixels, (uint16_t*)out, B, S, P, Kp);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+template <int NKP>
+static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int B, int T, int H, bool causal) {
+    const int lds = NKP * 32 * (128 + ATT_VSTRIDE);
+    if (causal) {
+        static bool done = false;
+        if (!done) {
+            MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKP, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            done = true;
+        }
+        hipLaunchKernelGGL((attention_kernel<NKP, true>), dim3(B * H), dim3(256), lds, st, (const uint16_t*)qkv,
+                           (uint16_t*)ctx, T, H);
+    } else {
+        static bool done = false;
+        if (!done) {
+            MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKP, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            done = true;
+        }
+        hipLaunchKernelGGL((attention_kernel<NKP, false>), dim3(B * H), dim3(256), lds, st, (const uint16_t*)qkv,
+                           (uint16_t*)ctx, T, H);
+    }
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+static int launch_attention(hipStream_t st, const void* qkv, void* ctx, int B, int T, int H, bool causal) {
+    if (B <= 0) return MMISS_OK;
+    if (T <= 0 || T > 288 || H <= 0) MM_FAIL(MMISS_ERR_UNSUPPORTED, "attention: T=%d (1..288), H=%d", T, H);
+    const int nkp = (T + 31) / 32;
+    // algorithmic flops: QK^T and PV, unpadded, full (non-causal) count as SURVEY.md §8(d) does
+    MM_PROF("attention", st, 4.0 * B * H * (double)T * T * 64, (double)B * T * H * 64 * 2 * 4);
+    switch (nkp) {
+        case 1: return launch_attention_nkp<1>(st, qkv, ctx, B, T, H, causal);
+        case 2: return launch_attention_nkp<2>(st, qkv, ctx, B, T, H, causal);
+        case 3: return launch_attention_nkp<3>(st, qkv, ctx, B, T, H, causal);
+        case 4: return launch_attention_nkp<4>(st, qkv, ctx, B, T, H, causal);
+        case 5: return launch_attention_nkp<5>(st, qkv, ctx, B, T, H, causal);
+        case 6: return launch_attention_nkp<6>(st, qkv, ctx, B, T, H, causal);
+        case 7: return launch_attention_nkp<7>(st, qkv, ctx, B, T, H, causal);
+        case 8: return launch_attention_nkp<8>(st, qkv, ctx, B, T, H, causal);
+        default: return launch_attention_nkp<9>(st, qkv, ctx, B, T, H, causal);
+    }
+}

@@ -1,0 +1,599 @@
+// retrieval_kernels.h — flat cosine index kernels (K10, K11, K12, X1 of SURVEY.md §2.2).
+//
+// What they replace: chromadb's cosine-space collection as the reference uses it
+// (backend/app/utils.py:127-130 create, backend/app/main.py:735-740 add, :761-765 query) — rows are
+// L2-normalised when added, a query returns the k rows of smallest cosine distance 1 - <q^, c^>.
+//
+// Exactness contract (DESIGN.md "retrieval parity"): selection runs in two stages.
+//   stage 1 (scan, HBM- or MFMA-bound): approximate scores on the matrix cores (f16 x f16 products are
+//     exact, fp32 accumulation in hardware order) with a fused running top-k' per wave, k' > k;
+//   stage 2 (rerank, negligible): the k' survivors are re-scored in a CANONICAL order in fp64
+//     (lane l sums d = l, l+64, ... sequentially; then a fixed xor-butterfly 32,16,..,1) and sorted by
+//     (distance asc, label asc). oracle/retrieval_oracle.c restates exactly that arithmetic, so ids AND
+//     distances are bit-identical between the two, on any shard layout.
+#pragma once
+#include "common.h"
+#include <math.h>
+#include <type_traits>
+
+#define SCAN_NEG_INF (-INFINITY)
+#define SCAN_ROW_NONE 0x7fffffff
+
+// ------------------------------------------------------------------------------------------------
+// canonical fp64 reductions (mirrored by oracle/retrieval_oracle.c: canon_dot / canon_sumsq)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_butterfly_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = v + __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ double widen(T v) { return (double)(float)v; }
+
+// ------------------------------------------------------------------------------------------------
+// K10: row normalisation at add time.  y = (float)((double)x / sqrt(canon_sumsq(x))), then the
+// storage rounding (f16: RNE from that float). One wave per row. D % 64 == 0.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                             int64_t n, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float* x = src + r * D;
+    double acc = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double v = (double)x[d];
+        acc = acc + v * v;
+    }
+    const double nrm = sqrt(wave_butterfly_sum(acc));
+    for (int d = lane; d < D; d += 64) {
+        const float y = (float)((double)x[d] / nrm);
+        dst[r * D + d] = (T)y;
+    }
+}
+
+// Query preparation: qn = canonical normalisation (f32, used by the rerank), qs = qn in the storage
+// dtype for the scan's MFMA operand, rows [Q, Qpad) zero-filled.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, float* __restrict__ qn,
+                                                           T* __restrict__ qs, int Q, int Qpad, int D) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= Qpad) return;
+    if (r >= Q) {
+        for (int d = lane; d < D; d += 64) qs[(size_t)r * D + d] = (T)0.0f;
+        return;
+    }
+    const float* x = q + (size_t)r * D;
+    double acc = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double v = (double)x[d];
+        acc = acc + v * v;
+    }
+    const double nrm = sqrt(wave_butterfly_sum(acc));
+    for (int d = lane; d < D; d += 64) {
+        const float y = (float)((double)x[d] / nrm);
+        qn[(size_t)r * D + d] = y;
+        qs[(size_t)r * D + d] = (T)y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// running top-k' list of one wave for one query, kept in LDS: append when a score beats the list's
+// threshold, compact (64-lane bitonic sort by (score desc, row asc)) when it fills up.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cand_better(float sa, int ra, float sb, int rb) {
+    return sa > sb || (sa == sb && ra < rb);
+}
+
+// sorts the 64 (s, r) pairs held one per lane: best first (bitonic network, 21 compare-exchange stages)
+__device__ __forceinline__ void wave_sort64_stage(float& s, int& r, int lane, int k, int j) {
+    const float os = __shfl_xor(s, j);
+    const int orr = __shfl_xor(r, j);
+    const bool lower = (lane & j) == 0;
+    const bool up = (lane & k) == 0;  // at k == 64 every lane is "up": final order best-first
+    const bool keep_best = (lower == up);
+    const bool take = keep_best ? cand_better(os, orr, s, r) : cand_better(s, r, os, orr);
+    if (take) { s = os; r = orr; }
+}
+__device__ __forceinline__ void wave_sort64(float& s, int& r, int lane) {
+    wave_sort64_stage(s, r, lane, 2, 1);
+    wave_sort64_stage(s, r, lane, 4, 2);  wave_sort64_stage(s, r, lane, 4, 1);
+    wave_sort64_stage(s, r, lane, 8, 4);  wave_sort64_stage(s, r, lane, 8, 2);  wave_sort64_stage(s, r, lane, 8, 1);
+    wave_sort64_stage(s, r, lane, 16, 8); wave_sort64_stage(s, r, lane, 16, 4); wave_sort64_stage(s, r, lane, 16, 2);
+    wave_sort64_stage(s, r, lane, 16, 1);
+    wave_sort64_stage(s, r, lane, 32, 16); wave_sort64_stage(s, r, lane, 32, 8); wave_sort64_stage(s, r, lane, 32, 4);
+    wave_sort64_stage(s, r, lane, 32, 2);  wave_sort64_stage(s, r, lane, 32, 1);
+    wave_sort64_stage(s, r, lane, 64, 32); wave_sort64_stage(s, r, lane, 64, 16); wave_sort64_stage(s, r, lane, 64, 8);
+    wave_sort64_stage(s, r, lane, 64, 4);  wave_sort64_stage(s, r, lane, 64, 2);  wave_sort64_stage(s, r, lane, 64, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11 stage 1: scan + fused top-k'.
+//
+// grid = (slabs, query tiles); block = 4 waves. A block owns NQ = 16*NQT queries (their MFMA B
+// fragments staged once into LDS, rows padded by 16 B so the 16 query rows of a fragment read hit 16
+// different bank groups) and a contiguous slab of 16-row tiles; wave w takes tiles w, w+4, ...
+// A fragments (corpus rows) go global -> VGPR directly: each byte of the corpus is used by exactly one
+// wave once (guide "GEMV / M <= 16" row: no LDS round trip for a streamed, unshared operand), 16-byte
+// loads, the K loop unrolled so 4-8 loads per lane are in flight.
+//   f16 rows: v_mfma_f32_16x16x32_f16 — lane (r = lane&15, g = lane>>4) feeds row r, k = 32s + 8g ..+7
+//   f32 rows: v_mfma_f32_16x16x4_f32 x4 per 16-byte load — lane feeds k = 16s + 4g + t to MFMA t
+//             (both operands use the same k permutation, so the dot product is unchanged)
+// Accumulator: D[row = 4g + reg][col = lane&15] -> a lane always owns the same query, so its threshold
+// lives in a register.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct ScanTraits;
+template <> struct ScanTraits<_Float16> { static constexpr int ELT = 2; };
+template <> struct ScanTraits<float> { static constexpr int ELT = 4; };
+
+struct ScanArgs {
+    const void* rows;     // [N, D] storage dtype
+    int64_t N;
+    int D;
+    const void* qs;       // [Qpad, D] storage dtype, Qpad % 16 == 0
+    int Q;
+    const float* cur_s;   // [Q] paging cursor (score, row) or null: only entries strictly after it pass
+    const int32_t* cur_r;
+    int kp;               // list length k'
+    int tiles_per_block;  // 16-row tiles per slab
+    float* out_s;         // [gridDim.x][Q][kp]
+    int32_t* out_r;
+};
+
+template <int NQT, int CAP>
+struct ScanLds {
+    // byte offsets inside dynamic LDS
+    int qstride;  // bytes per query row
+    int off_cs, off_cr, off_cnt, off_tau, total;
+    __host__ __device__ ScanLds(int D, int elt) {
+        qstride = D * elt + 16;
+        const int NQ = 16 * NQT;
+        off_cs = (int)round_up16(NQ * qstride);
+        off_cr = off_cs + 4 * NQ * CAP * 4;
+        off_cnt = off_cr + 4 * NQ * CAP * 4;
+        off_tau = off_cnt + 4 * NQ * 4;
+        total = off_tau + 4 * NQ * 4;
+    }
+    static __host__ __device__ int round_up16(int x) { return (x + 15) & ~15; }
+};
+
+template <typename T, int NQT, int CAP>
+__global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ELT = ScanTraits<T>::ELT;
+    constexpr int NQ = 16 * NQT;
+    const ScanLds<NQT, CAP> L(a.D, ELT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qbase = blockIdx.y * NQ;
+    const int D = a.D;
+
+    char* sQ = smem;
+    float* cs = reinterpret_cast<float*>(smem + L.off_cs) + wave * NQ * CAP;
+    int* cr = reinterpret_cast<int*>(smem + L.off_cr) + wave * NQ * CAP;
+    int* cnt = reinterpret_cast<int*>(smem + L.off_cnt) + wave * NQ;
+    float* tau = reinterpret_cast<float*>(smem + L.off_tau) + wave * NQ;
+
+    // stage the query block (16-byte chunks), init list state
+    {
+        const int chunks_per_row = D * ELT / 16;
+        const char* qsrc = reinterpret_cast<const char*>(a.qs) + (size_t)qbase * D * ELT;
+        for (int i = tid; i < NQ * chunks_per_row; i += 256) {
+            const int qr = i / chunks_per_row, c = i - qr * chunks_per_row;
+            *reinterpret_cast<u32x4*>(sQ + qr * L.qstride + c * 16) =
+                *reinterpret_cast<const u32x4*>(qsrc + ((size_t)qr * chunks_per_row + c) * 16);
+        }
+        for (int i = lane; i < NQ; i += 64) { cnt[i] = 0; tau[i] = SCAN_NEG_INF; }
+    }
+    __syncthreads();
+
+    float tau_r[NQT], cur_s[NQT];
+    int cur_r[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        tau_r[qt] = SCAN_NEG_INF;
+        const int q = qbase + qt * 16 + fr;
+        cur_s[qt] = (a.cur_s && q < a.Q) ? a.cur_s[q] : INFINITY;
+        cur_r[qt] = (a.cur_r && q < a.Q) ? a.cur_r[q] : -1;
+    }
+
+    // compaction of every list of this wave that is longer than kp (wave-uniform control flow)
+    auto compact_all = [&]() {
+        for (int ql = 0; ql < NQ; ++ql) {
+            const int c = cnt[ql];
+            if (c > a.kp) {
+                float s = SCAN_NEG_INF;
+                int r = SCAN_ROW_NONE;
+                if (lane < c && lane < CAP) { s = cs[ql * CAP + lane]; r = cr[ql * CAP + lane]; }
+                wave_sort64(s, r, lane);
+                if (lane < a.kp) { cs[ql * CAP + lane] = s; cr[ql * CAP + lane] = r; }
+                const float t = __shfl(s, a.kp - 1);
+                if (lane == 0) { cnt[ql] = a.kp; tau[ql] = t; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) tau_r[qt] = tau[qt * 16 + fr];
+    };
+
+    const int64_t ntiles_total = (a.N + 15) >> 4;
+    const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_block;
+    int64_t tile_end = tile0 + a.tiles_per_block;
+    if (tile_end > ntiles_total) tile_end = ntiles_total;
+
+    for (int64_t tile = tile0 + wave; tile < tile_end; tile += 4) {
+        const int64_t row0 = tile << 4;
+        int64_t rload = row0 + fr;
+        if (rload >= a.N) rload = a.N - 1;  // clamp: loads stay in bounds, the result is masked below
+        const char* rp = reinterpret_cast<const char*>(a.rows) + (size_t)rload * D * ELT + fg * 16;
+        const char* qp = sQ + fr * L.qstride + fg * 16;
+        f32x4 acc[NQT];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // 64 bytes of every row per step (4 lanes x 16 B); steps are issued in groups of 8 (then 4) with all
+        // the group's global loads ahead of its MFMAs, so 8 (4) 1-KiB wave-loads are in flight per wave
+        auto steps = [&](auto nsteps_tag, int byte0) {
+            constexpr int NS = decltype(nsteps_tag)::value;
+            u32x4 araw[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) araw[s] = *reinterpret_cast<const u32x4*>(rp + byte0 + s * 64);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt) {
+                    const u32x4 braw = *reinterpret_cast<const u32x4*>(qp + qt * 16 * L.qstride + byte0 + s * 64);
+                    if constexpr (ELT == 2) {
+                        acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, araw[s]),
+                                                                         __builtin_bit_cast(f16x8, braw), acc[qt], 0, 0, 0);
+                    } else {
+                        const f32x4 af = __builtin_bit_cast(f32x4, araw[s]), bf = __builtin_bit_cast(f32x4, braw);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t], bf[t], acc[qt], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        const int row_bytes = D * ELT;  // a multiple of 256 (checked on the host)
+        int byte0 = 0;
+        for (; byte0 + 512 <= row_bytes; byte0 += 512) steps(std::integral_constant<int, 8>{}, byte0);
+        if (byte0 < row_bytes) steps(std::integral_constant<int, 4>{}, byte0);
+        // filter + append
+        bool need = false;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            const int ql = qt * 16 + fr;
+            const bool qok = (qbase + ql) < a.Q;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t row = row0 + 4 * fg + reg;
+                const float s = acc[qt][reg];
+                const int ri = (int)row;
+                const bool after = (s < cur_s[qt]) || (s == cur_s[qt] && ri > cur_r[qt]);
+                if (qok && row < a.N && s > tau_r[qt] && after) {
+                    const int pos = atomicAdd(&cnt[ql], 1);
+                    cs[ql * CAP + pos] = s;
+                    cr[ql * CAP + pos] = ri;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) need |= cnt[qt * 16 + fr] > CAP - 16;
+        if (__any(need)) compact_all();
+    }
+
+    // block merge: the 4 waves' lists of one query -> one list of kp, written to out[blockIdx.x][q][:]
+    compact_all();
+    __syncthreads();
+    float* cs_all = reinterpret_cast<float*>(smem + L.off_cs);
+    int* cr_all = reinterpret_cast<int*>(smem + L.off_cr);
+    int* cnt_all = reinterpret_cast<int*>(smem + L.off_cnt);
+    for (int ql = wave; ql < NQ; ql += 4) {
+        const int q = qbase + ql;
+        if (q >= a.Q) continue;
+        float s = SCAN_NEG_INF;
+        int r = SCAN_ROW_NONE;
+        const int c0 = cnt_all[0 * NQ + ql];
+        if (lane < c0) { s = cs_all[(0 * NQ + ql) * CAP + lane]; r = cr_all[(0 * NQ + ql) * CAP + lane]; }
+        for (int w = 1; w < 4; ++w) {
+            const int cw = cnt_all[w * NQ + ql];
+            // the running list sits in lanes [0, kp) (kp <= 32), the next wave's list goes to lanes [32, 32+cw)
+            if (lane >= a.kp) { s = SCAN_NEG_INF; r = SCAN_ROW_NONE; }
+            if (lane >= 32 && lane - 32 < cw) {
+                s = cs_all[(w * NQ + ql) * CAP + lane - 32];
+                r = cr_all[(w * NQ + ql) * CAP + lane - 32];
+            }
+            wave_sort64(s, r, lane);
+        }
+        if (lane < a.kp) {
+            const size_t o = ((size_t)blockIdx.x * a.Q + q) * a.kp + lane;
+            a.out_s[o] = s;
+            a.out_r[o] = (r == SCAN_ROW_NONE) ? -1 : r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11 stage 1b: merge the per-slab lists of one query into the query's top-k' (same filter +
+// compact machinery, entries streamed 64 per wave-instruction). One block per query.
+// Writes the page into cand[q][page_off .. page_off+kp) and advances the paging cursor.
+// ------------------------------------------------------------------------------------------------
+struct MergeArgs {
+    const float* in_s;    // [L][Q][kp]
+    const int32_t* in_r;
+    int L, Q, kp;
+    int32_t* cand;        // [Q][cand_stride] row ids, -1 = none
+    int cand_stride, page_off;
+    float* cur_s;         // [Q] cursor, updated to the page's last entry (or -inf when exhausted); may be null
+    int32_t* cur_r;
+};
+
+// A wave streams 32 entries per step, so a list of <= kp (<= 32) entries can never outgrow its 64-slot
+// buffer before the compaction that follows the step.
+__global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
+    __shared__ float cs[4][64];
+    __shared__ int cr[4][64];
+    __shared__ int cnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int kp = a.kp;  // <= 32
+    if (lane == 0) cnt[wave] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    float tau = SCAN_NEG_INF;
+    const int64_t total = (int64_t)a.L * kp;
+    for (int64_t e0 = (int64_t)wave * 32; e0 < total; e0 += 128) {
+        const int64_t e = e0 + (lane & 31);
+        float s = SCAN_NEG_INF;
+        int r = -1;
+        if (lane < 32 && e < total) {
+            const int64_t l = e / kp;
+            const int slot = (int)(e - l * kp);
+            const size_t o = ((size_t)l * a.Q + q) * kp + slot;
+            s = a.in_s[o];
+            r = a.in_r[o];
+        }
+        if (r >= 0 && s > tau) {
+            const int pos = atomicAdd(&cnt[wave], 1);
+            cs[wave][pos] = s;
+            cr[wave][pos] = r;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int c = cnt[wave];
+        if (c > kp) {
+            float ss = SCAN_NEG_INF;
+            int rr = SCAN_ROW_NONE;
+            if (lane < c) { ss = cs[wave][lane]; rr = cr[wave][lane]; }
+            wave_sort64(ss, rr, lane);
+            if (lane < kp) { cs[wave][lane] = ss; cr[wave][lane] = rr; }
+            tau = __shfl(ss, kp - 1);
+            if (lane == 0) cnt[wave] = kp;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float s = SCAN_NEG_INF;
+        int r = SCAN_ROW_NONE;
+        const int c0 = cnt[0];
+        if (lane < c0) { s = cs[0][lane]; r = cr[0][lane]; }
+        // sort the first list too (it may never have been compacted)
+        wave_sort64(s, r, lane);
+        for (int w = 1; w < 4; ++w) {
+            const int cw = cnt[w];
+            if (lane >= kp) { s = SCAN_NEG_INF; r = SCAN_ROW_NONE; }
+            if (lane >= 32 && lane - 32 < cw) { s = cs[w][lane - 32]; r = cr[w][lane - 32]; }
+            wave_sort64(s, r, lane);
+        }
+        const bool valid = lane < kp && r != SCAN_ROW_NONE;
+        if (lane < kp) a.cand[(size_t)q * a.cand_stride + a.page_off + lane] = valid ? r : -1;
+        if (a.cur_s) {
+            const unsigned long long m = __ballot(valid);
+            const int nvalid = __popcll(m);
+            const float ls = __shfl(s, nvalid > 0 ? nvalid - 1 : 0);
+            const int lr = __shfl(r, nvalid > 0 ? nvalid - 1 : 0);
+            if (lane == 0) {
+                if (nvalid == kp) { a.cur_s[q] = ls; a.cur_r[q] = lr; }
+                else { a.cur_s[q] = SCAN_NEG_INF; a.cur_r[q] = SCAN_ROW_NONE; }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K11 stage 2: canonical rerank + final ordering. One block per query.
+//   dist(q, c) = (float)(1.0 - canon_dot(qn, row))   — fp64, fixed order (see file header)
+//   order      = (dist asc, label asc)
+// ncand <= 2048 candidates per query (row ids, -1 = none).
+// ------------------------------------------------------------------------------------------------
+struct RerankArgs {
+    const void* rows; int D;
+    const float* qn;        // [Q, D] canonical-normalised queries
+    const int32_t* cand;    // [Q][cand_stride]
+    int cand_stride, ncand;
+    const int64_t* labels;  // [N] row -> label
+    int k;
+    int64_t* out_labels;    // [Q, k]
+    float* out_dist;        // [Q, k]
+    int32_t* out_count;     // [Q]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // sort buffer: npow2 entries of (dist f32, label i64)
+    int npow = 1;
+    while (npow < a.ncand) npow <<= 1;
+    float* sd = reinterpret_cast<float*>(smem);
+    int64_t* sl = reinterpret_cast<int64_t*>(smem + (size_t)npow * 4 + ((npow & 1) ? 4 : 0));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const float* qv = a.qn + (size_t)q * a.D;
+    for (int i = tid; i < npow; i += 256) { sd[i] = INFINITY; sl[i] = INT64_MAX; }
+    __syncthreads();
+    for (int c = wave; c < a.ncand; c += 4) {
+        const int row = a.cand[(size_t)q * a.cand_stride + c];
+        if (row < 0) continue;  // wave-uniform
+        const T* rv = reinterpret_cast<const T*>(a.rows) + (size_t)row * a.D;
+        double acc = 0.0;
+        for (int d = lane; d < a.D; d += 64) acc = acc + (double)qv[d] * widen<T>(rv[d]);
+        const double dot = wave_butterfly_sum(acc);
+        if (lane == 0) {
+            sd[c] = (float)(1.0 - dot);
+            sl[c] = a.labels[row];
+        }
+    }
+    __syncthreads();
+    // block bitonic sort ascending by (dist, label); NaN distances sort last
+    for (int k = 2; k <= npow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow; i += 256) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float di = sd[i], dp = sd[p];
+                    const int64_t li = sl[i], lp = sl[p];
+                    const bool up = (i & k) == 0;
+                    // "i before p" in the final order?
+                    const bool i_first = (di < dp) || (di == dp && li < lp) || (dp != dp && di == di);
+                    const bool p_first = (dp < di) || (dp == di && lp < li) || (di != di && dp == dp);
+                    const bool swap = up ? p_first : i_first;
+                    if (swap) { sd[i] = dp; sd[p] = di; sl[i] = lp; sl[p] = li; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int nvalid = 0;
+    for (int i = tid; i < a.k; i += 256) {
+        const bool ok = i < npow && sl[i] != INT64_MAX;
+        a.out_labels[(size_t)q * a.k + i] = ok ? sl[i] : -1;
+        a.out_dist[(size_t)q * a.k + i] = ok ? sd[i] : INFINITY;
+    }
+    if (tid == 0) {
+        const int lim = a.k < npow ? a.k : npow;
+        for (int i = 0; i < lim; ++i) nvalid += (sl[i] != INT64_MAX);
+        a.out_count[q] = nvalid;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K12: multimodal blend (backend/app/main.py:852-860), one wave per query:
+//   i^ = i/|i|, t^ = t/|t| (canonical fp64 norms, rounded to f32 like the index rows),
+//   c = (float)w * i^ + (float)(1-w) * t^   (two f32 multiplies and one f32 add, as numpy evaluates it),
+//   out = c/|c|.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ img, const float* __restrict__ txt,
+                                                    float w_img, float w_txt, int Q, int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= Q) return;
+    const float* xi = img + (size_t)r * D;
+    const float* xt = txt + (size_t)r * D;
+    double ai = 0.0, at = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double vi = (double)xi[d], vt = (double)xt[d];
+        ai = ai + vi * vi;
+        at = at + vt * vt;
+    }
+    const double ni = sqrt(wave_butterfly_sum(ai)), nt = sqrt(wave_butterfly_sum(at));
+    double ac = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const float yi = (float)((double)xi[d] / ni), yt = (float)((double)xt[d] / nt);
+        const float c = __fadd_rn(__fmul_rn(w_img, yi), __fmul_rn(w_txt, yt));
+        ac = ac + (double)c * (double)c;
+    }
+    const double nc = sqrt(wave_butterfly_sum(ac));
+    for (int d = lane; d < D; d += 64) {
+        const float yi = (float)((double)xi[d] / ni), yt = (float)((double)xt[d] / nt);
+        const float c = __fadd_rn(__fmul_rn(w_img, yi), __fmul_rn(w_txt, yt));
+        out[(size_t)r * D + d] = (float)((double)c / nc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// X1 tail: merge S gathered per-shard result lists into the global top-k by (dist asc, label asc).
+// One block per query, S*k <= 4096 entries.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shard_merge_kernel(const float* __restrict__ dist, const int64_t* __restrict__ labels,
+                                                          int S, int Q, int k, float* __restrict__ out_dist,
+                                                          int64_t* __restrict__ out_labels, int32_t* __restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = S * k;
+    int npow = 1;
+    while (npow < n) npow <<= 1;
+    float* sd = reinterpret_cast<float*>(smem);
+    int64_t* sl = reinterpret_cast<int64_t*>(smem + (size_t)npow * 4 + ((npow & 1) ? 4 : 0));
+    const int tid = threadIdx.x, q = blockIdx.x;
+    for (int i = tid; i < npow; i += 256) {
+        float d = INFINITY;
+        int64_t l = INT64_MAX;
+        if (i < n) {
+            const int s = i / k, j = i - s * k;
+            const size_t o = ((size_t)s * Q + q) * k + j;
+            const int64_t ll = labels[o];
+            if (ll >= 0) { l = ll; d = dist[o]; }
+        }
+        sd[i] = d;
+        sl[i] = l;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= npow; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow; i += 256) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const float di = sd[i], dp = sd[p];
+                    const int64_t li = sl[i], lp = sl[p];
+                    const bool up = (i & kk) == 0;
+                    const bool i_first = (di < dp) || (di == dp && li < lp) || (dp != dp && di == di);
+                    const bool p_first = (dp < di) || (dp == di && lp < li) || (di != di && dp == dp);
+                    const bool swap = up ? p_first : i_first;
+                    if (swap) { sd[i] = dp; sd[p] = di; sl[i] = lp; sl[p] = li; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 256) {
+        const bool ok = i < npow && sl[i] != INT64_MAX;
+        out_labels[(size_t)q * k + i] = ok ? sl[i] : -1;
+        out_dist[(size_t)q * k + i] = ok ? sd[i] : INFINITY;
+    }
+    if (tid == 0 && out_count) {
+        int c = 0;
+        const int lim = k < npow ? k : npow;
+        for (int i = 0; i < lim; ++i) c += (sl[i] != INT64_MAX);
+        out_count[q] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row movement for stable removal and for "get": dst[i] = src[map[i]] (rows of D elements)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ map,
+                                                          T* __restrict__ dst, int64_t n, int D) {
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int d = (int)(i - r * D);
+        dst[i] = src[map[r] * D + d];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const T* __restrict__ src, const int64_t* __restrict__ map,
+                                                              float* __restrict__ dst, int64_t n, int D) {
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int d = (int)(i - r * D);
+        dst[i] = (float)src[map[r] * D + d];
+    }
+}
+__global__ void gather_i64_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ map,
+                                  int64_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[map[i]];
+}

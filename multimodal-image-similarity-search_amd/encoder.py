@@ -1,0 +1,187 @@
+"""ClipEncoder — batched CLIP image / text towers on one MI355X through libmmiss.
+
+The arithmetic replaced is `model.get_image_features(**inputs)` / `model.get_text_features(**inputs)`
+followed by the L2 normalisation in backend/app/utils.py:77-78,97-98 of the reference. Weights use the
+HF state_dict key layout (SURVEY.md §8 a-W), so a local HF checkpoint loads unchanged.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, asdict
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class ClipShape:
+    """Shape of both towers; defaults = HF CLIPConfig() = ViT-B/32 (HF:configuration_clip.py:47-54,97-105,160)."""
+
+    v_hidden: int = 768
+    v_layers: int = 12
+    v_heads: int = 12
+    v_mlp: int = 3072
+    v_patch: int = 32
+    v_image: int = 224
+    t_hidden: int = 512
+    t_layers: int = 12
+    t_heads: int = 8
+    t_mlp: int = 2048
+    t_vocab: int = 49408
+    t_ctx: int = 77
+    proj_dim: int = 512
+    eos_token_id: int = 49407
+    ln_eps: float = 1e-5
+
+    @classmethod
+    def from_any(cls, obj) -> "ClipShape":
+        """Accepts another dataclass / dict with the same field names (e.g. the oracle's ClipShape)."""
+        if isinstance(obj, cls):
+            return obj
+        d = obj if isinstance(obj, dict) else asdict(obj)
+        return cls(**{k: d[k] for k in cls.__dataclass_fields__})
+
+    @classmethod
+    def from_hf_config(cls, cfg) -> "ClipShape":
+        """From a transformers CLIPConfig (or its dict): the reference builds one at utils.py:41-42."""
+        d = cfg.to_dict() if hasattr(cfg, "to_dict") else dict(cfg)
+        v, t = d["vision_config"], d["text_config"]
+        return cls(v_hidden=v["hidden_size"], v_layers=v["num_hidden_layers"], v_heads=v["num_attention_heads"],
+                   v_mlp=v["intermediate_size"], v_patch=v["patch_size"], v_image=v["image_size"],
+                   t_hidden=t["hidden_size"], t_layers=t["num_hidden_layers"], t_heads=t["num_attention_heads"],
+                   t_mlp=t["intermediate_size"], t_vocab=t["vocab_size"], t_ctx=t["max_position_embeddings"],
+                   proj_dim=d.get("projection_dim", v.get("projection_dim", 512)),
+                   eos_token_id=t.get("eos_token_id", 49407) if t.get("eos_token_id") is not None else 49407,
+                   ln_eps=v.get("layer_norm_eps", 1e-5))
+
+    @property
+    def v_tokens(self) -> int:
+        return (self.v_image // self.v_patch) ** 2 + 1
+
+
+VIT_B32 = ClipShape()
+LONGCLIP_L14 = ClipShape(v_hidden=1024, v_layers=24, v_heads=16, v_mlp=4096, v_patch=14, v_image=224,
+                         t_hidden=768, t_layers=12, t_heads=12, t_mlp=3072, t_ctx=248, proj_dim=768)
+
+
+def _is_torch(x) -> bool:
+    return hasattr(x, "data_ptr")
+
+
+class ClipEncoder:
+    """One encoder handle = both towers' weights in HBM + workspaces, on one GPU, one HIP stream."""
+
+    def __init__(self, shape: ClipShape = VIT_B32, device: int = 0, max_batch_image: int = 256,
+                 max_batch_text: int = 256):
+        self.shape = ClipShape.from_any(shape)
+        self.device = int(device)
+        self._lib = _lib.load()
+        s = self.shape
+        cfg = _lib.ClipConfigStruct(
+            C.sizeof(_lib.ClipConfigStruct), s.v_hidden, s.v_layers, s.v_heads, s.v_mlp, s.v_patch, s.v_image,
+            s.t_hidden, s.t_layers, s.t_heads, s.t_mlp, s.t_vocab, s.t_ctx, s.proj_dim, s.eos_token_id,
+            float(s.ln_eps), int(max_batch_image), int(max_batch_text))
+        h = C.c_void_p()
+        _lib.check(self._lib.mmiss_encoder_create(C.byref(cfg), self.device, C.byref(h)))
+        self._h = h
+        self._finalized = False
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state: Dict[str, "np.ndarray"]) -> Tuple[int, int]:
+        """state: HF key -> float32 array (numpy or torch CPU tensor). Returns (used, ignored)."""
+        used = ignored = 0
+        for key, val in state.items():
+            if _is_torch(val):
+                val = val.detach().to("cpu").float().contiguous().numpy()
+            arr = np.ascontiguousarray(val, dtype=np.float32)
+            u = C.c_int(0)
+            _lib.check(self._lib.mmiss_encoder_set_weight(self._h, key.encode(), arr.ctypes.data, arr.size, C.byref(u)))
+            used += u.value
+            ignored += 1 - u.value
+        _lib.check(self._lib.mmiss_encoder_finalize(self._h))
+        self._finalized = True
+        return used, ignored
+
+    def load_safetensors(self, path: str) -> Tuple[int, int]:
+        """Load a local HF-layout checkpoint (`model.safetensors`); no network access is attempted."""
+        from safetensors import safe_open
+
+        state = {}
+        with safe_open(path, framework="np") as f:
+            for k in f.keys():
+                state[k] = f.get_tensor(k).astype(np.float32)
+        return self.load_state_dict(state)
+
+    # ------------------------------------------------------------------ encode
+    def _out(self, like, n: int):
+        if _is_torch(like) and like.is_cuda:
+            import torch
+
+            return torch.empty((n, self.shape.proj_dim), dtype=torch.float32, device=like.device)
+        return np.empty((n, self.shape.proj_dim), dtype=np.float32)
+
+    def _sync_stream(self, x):
+        if _is_torch(x) and x.is_cuda:
+            _lib.check(self._lib.mmiss_encoder_set_stream(self._h, _lib.current_stream_ptr(x.device)))
+        else:
+            _lib.check(self._lib.mmiss_encoder_set_stream(self._h, None))
+
+    def encode_image(self, pixels, out=None):
+        """pixels: float32 [B,3,S,S] CLIP-normalised (numpy, or torch tensor on this GPU) -> float32 [B,proj] unit rows
+        (same container kind as the input). uint8 [B,S,S,3] input takes the fused rescale+normalise path."""
+        s = self.shape
+        is_u8 = (pixels.dtype == np.uint8) if not _is_torch(pixels) else (str(pixels.dtype) == "torch.uint8")
+        want = (s.v_image, s.v_image, 3) if is_u8 else (3, s.v_image, s.v_image)
+        if tuple(pixels.shape[1:]) != want:
+            raise ValueError(f"pixels must be [B,{','.join(map(str, want))}], got {tuple(pixels.shape)}")
+        if not _is_torch(pixels):
+            pixels = np.ascontiguousarray(pixels, dtype=np.uint8 if is_u8 else np.float32)
+        elif not is_u8 and str(pixels.dtype) != "torch.float32":
+            pixels = pixels.float()
+        if _is_torch(pixels):
+            pixels = pixels.contiguous()
+        B = int(pixels.shape[0])
+        out = self._out(pixels, B) if out is None else out
+        self._sync_stream(pixels)
+        fn = self._lib.mmiss_encode_image_u8 if is_u8 else self._lib.mmiss_encode_image
+        _lib.check(fn(self._h, _lib.ptr(pixels), B, _lib.ptr(out)))
+        return out
+
+    def encode_text(self, input_ids, out=None):
+        """input_ids: int [B,T] (T <= context length), rows = BOS ... EOS, padding -> float32 [B,proj] unit rows."""
+        if _is_torch(input_ids):
+            import torch
+
+            ids = input_ids.to(torch.int32).contiguous()
+        else:
+            ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        if ids.ndim != 2:
+            raise ValueError("input_ids must be [B,T]")
+        B, T = int(ids.shape[0]), int(ids.shape[1])
+        out = self._out(ids, B) if out is None else out
+        self._sync_stream(ids)
+        _lib.check(self._lib.mmiss_encode_text(self._h, _lib.ptr(ids), B, T, _lib.ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ debug
+    def record_taps(self, on: bool = True):
+        _lib.check(self._lib.mmiss_dbg_encoder_record_taps(self._h, 1 if on else 0))
+
+    def tap(self, tower: int, what: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.float32)
+        w = C.c_int64(0)
+        _lib.check(self._lib.mmiss_encoder_tap(self._h, tower, what, out.ctypes.data, n, C.byref(w)))
+        return out[: w.value]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mmiss_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

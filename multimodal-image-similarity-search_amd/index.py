@@ -1,0 +1,187 @@
+"""FlatIndex — one shard of the in-HBM flat cosine index (libmmiss `mmiss_index_*`).
+
+Numeric half of the chromadb Collection the reference creates with {"hnsw:space": "cosine"}
+(backend/app/utils.py:127-130): rows are L2-normalised when added; a query returns the k rows of
+smallest cosine distance 1 - cos, ascending, ties by label ascending.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+F32, F16 = _lib.MMISS_F32, _lib.MMISS_F16
+_DTYPES = {"f32": F32, "float32": F32, "f16": F16, "float16": F16, F32: F32, F16: F16}
+
+
+def _is_torch(x) -> bool:
+    return hasattr(x, "data_ptr")
+
+
+class FlatIndex:
+    def __init__(self, dim: int, dtype="f32", device: int = 0, capacity: int = 0):
+        self.dim = int(dim)
+        self.dtype = _DTYPES[dtype]
+        self.device = int(device)
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.mmiss_index_create(self.dim, self.dtype, self.device, int(capacity), C.byref(h)))
+        self._h = h
+
+    # ------------------------------------------------------------------ helpers
+    def _vecs(self, v):
+        if _is_torch(v):
+            import torch
+
+            v = v.to(torch.float32).contiguous()
+        else:
+            v = np.ascontiguousarray(v, dtype=np.float32)
+        if v.ndim == 1:
+            v = v.reshape(1, -1)
+        if v.ndim != 2 or v.shape[1] != self.dim:
+            raise ValueError(f"expected [n,{self.dim}] vectors, got {tuple(v.shape)}")
+        return v
+
+    def _sync_stream(self, x):
+        if _is_torch(x) and x.is_cuda:
+            _lib.check(self._lib.mmiss_index_set_stream(self._h, _lib.current_stream_ptr(x.device)))
+        else:
+            _lib.check(self._lib.mmiss_index_set_stream(self._h, None))
+
+    # ------------------------------------------------------------------ mutation
+    def add(self, vecs, labels) -> None:
+        v = self._vecs(vecs)
+        lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
+        if lab.shape[0] != v.shape[0]:
+            raise ValueError("labels and vectors differ in length")
+        self._sync_stream(v)
+        _lib.check(self._lib.mmiss_index_add(self._h, _lib.ptr(v), lab.ctypes.data, int(v.shape[0])))
+
+    def update(self, labels, vecs) -> None:
+        v = self._vecs(vecs)
+        lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
+        self._sync_stream(v)
+        _lib.check(self._lib.mmiss_index_update(self._h, lab.ctypes.data, _lib.ptr(v), int(v.shape[0])))
+
+    def remove(self, labels) -> int:
+        lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
+        n = C.c_int64(0)
+        _lib.check(self._lib.mmiss_index_remove(self._h, lab.ctypes.data, int(lab.shape[0]), C.byref(n)))
+        return n.value
+
+    def clear(self) -> None:
+        _lib.check(self._lib.mmiss_index_clear(self._h))
+
+    # ------------------------------------------------------------------ read
+    def count(self) -> int:
+        n = C.c_int64(0)
+        _lib.check(self._lib.mmiss_index_count(self._h, C.byref(n)))
+        return n.value
+
+    def __len__(self) -> int:
+        return self.count()
+
+    def labels(self) -> np.ndarray:
+        n = self.count()
+        out = np.empty(n, dtype=np.int64)
+        _lib.check(self._lib.mmiss_index_labels(self._h, out.ctypes.data, n))
+        return out
+
+    def get(self, labels) -> np.ndarray:
+        lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
+        out = np.empty((lab.shape[0], self.dim), dtype=np.float32)
+        if lab.shape[0]:
+            _lib.check(self._lib.mmiss_index_get(self._h, lab.ctypes.data, int(lab.shape[0]), out.ctypes.data))
+        return out
+
+    def query(self, queries, k: int) -> Tuple["np.ndarray", "np.ndarray", "np.ndarray"]:
+        """-> (labels int64 [Q,k], distances float32 [Q,k], counts int32 [Q]); numpy in -> numpy out,
+        CUDA tensor in -> CUDA tensors out (no host round trip)."""
+        q = self._vecs(queries)
+        Q = int(q.shape[0])
+        if _is_torch(q) and q.is_cuda:
+            import torch
+
+            lab = torch.empty((Q, k), dtype=torch.int64, device=q.device)
+            dist = torch.empty((Q, k), dtype=torch.float32, device=q.device)
+            cnt = torch.empty((Q,), dtype=torch.int32, device=q.device)
+        else:
+            if _is_torch(q):
+                q = q.numpy()
+            lab = np.empty((Q, k), dtype=np.int64)
+            dist = np.empty((Q, k), dtype=np.float32)
+            cnt = np.empty((Q,), dtype=np.int32)
+        self._sync_stream(q)
+        _lib.check(self._lib.mmiss_index_query(self._h, _lib.ptr(q), Q, int(k), _lib.ptr(lab), _lib.ptr(dist), _lib.ptr(cnt)))
+        return lab, dist, cnt
+
+    # ------------------------------------------------------------------ persistence
+    def save(self, path: str) -> None:
+        _lib.check(self._lib.mmiss_index_save(self._h, str(path).encode()))
+
+    def load(self, path: str) -> None:
+        _lib.check(self._lib.mmiss_index_load(self._h, str(path).encode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mmiss_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def blend(img, txt, weight_image: float, device: int = 0):
+    """normalize(w * normalize(img) + (1 - w) * normalize(txt)) row-wise — backend/app/main.py:852-860."""
+    lib = _lib.load()
+    if _is_torch(img) and img.is_cuda:
+        import torch
+
+        img = img.to(torch.float32).contiguous()
+        txt = txt.to(torch.float32).contiguous()
+        out = torch.empty_like(img)
+        stream = _lib.current_stream_ptr(img.device)
+        device = img.device.index if img.device.index is not None else device
+    else:
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        txt = np.ascontiguousarray(txt, dtype=np.float32)
+        out = np.empty_like(img)
+        stream = None
+    one_d = img.ndim == 1
+    Q = 1 if one_d else int(img.shape[0])
+    D = int(img.shape[-1])
+    if tuple(img.shape) != tuple(txt.shape):
+        raise ValueError("image and text embeddings differ in shape")
+    _lib.check(lib.mmiss_blend(device, stream, _lib.ptr(img), _lib.ptr(txt), float(weight_image), Q, D, _lib.ptr(out)))
+    return out
+
+
+def merge_topk(dist, labels, device: int = 0):
+    """dist [S,Q,k] f32, labels [S,Q,k] i64 (per-shard results) -> (labels [Q,k], dist [Q,k], count [Q])."""
+    lib = _lib.load()
+    S, Q, k = (int(x) for x in dist.shape)
+    if _is_torch(dist) and dist.is_cuda:
+        import torch
+
+        dist = dist.contiguous()
+        labels = labels.contiguous()
+        od = torch.empty((Q, k), dtype=torch.float32, device=dist.device)
+        ol = torch.empty((Q, k), dtype=torch.int64, device=dist.device)
+        oc = torch.empty((Q,), dtype=torch.int32, device=dist.device)
+        stream = _lib.current_stream_ptr(dist.device)
+        device = dist.device.index if dist.device.index is not None else device
+    else:
+        dist = np.ascontiguousarray(dist, dtype=np.float32)
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        od = np.empty((Q, k), dtype=np.float32)
+        ol = np.empty((Q, k), dtype=np.int64)
+        oc = np.empty((Q,), dtype=np.int32)
+        stream = None
+    _lib.check(lib.mmiss_merge_topk(device, stream, _lib.ptr(dist), _lib.ptr(labels), S, Q, k, _lib.ptr(od), _lib.ptr(ol), _lib.ptr(oc)))
+    return ol, od, oc

@@ -1,0 +1,133 @@
+"""CLIP towers on the MI355X vs oracle/clip_oracle.py (numpy fp32, itself pinned against transformers'
+CLIPModel): embeddings within 1e-3 cosine (north_star tolerance), intermediates bisected per layer."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-3  # BASELINE.json north_star: "within 1e-3 cosine of the reference CPU path"
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    W = co.init_weights(co.TINY, seed=0)
+    enc = ClipEncoder(ClipShape.from_any(co.TINY), max_batch_image=8, max_batch_text=8)
+    enc.record_taps(True)
+    used, ignored = enc.load_state_dict(W)
+    assert ignored == 0 and used == len(W)
+    return enc, W, co
+
+
+def _cos(a, b):
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def test_tiny_image_tower_layer_by_layer(tiny):
+    enc, W, co = tiny
+    s = co.TINY
+    rng = np.random.Generator(np.random.Philox(5))
+    px = rng.standard_normal((5, 3, s.v_image, s.v_image), dtype=np.float32)
+    out = enc.encode_image(px)
+    taps = {}
+    ref = co.l2_normalize(co.image_features(px, W, s, taps))
+    T, d = s.v_tokens, s.v_hidden
+    for l in range(s.v_layers + 1):
+        got = enc.tap(0, l, 5 * T * d).reshape(5, T, d)
+        err = np.abs(got - taps[l]).max()
+        scale = np.abs(taps[l]).max()
+        assert err < 0.03 * scale, f"layer {l}: err {err} scale {scale}"
+    assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
+    assert (1 - _cos(out, ref)).max() < COS_TOL
+
+
+def test_tiny_text_tower_and_short_sequences(tiny):
+    enc, W, co = tiny
+    s = co.TINY
+    ids = co.synthetic_text_ids(7, s.t_ctx, s.t_vocab, s.eos_token_id, seed=3)
+    out = enc.encode_text(ids)
+    ref = co.embed_texts(ids, W, s)
+    assert (1 - _cos(out, ref)).max() < COS_TOL
+    # a shorter T (fewer pad columns) must give the same embeddings when every row's EOS is inside
+    eos = co.eos_positions(ids, s.eos_token_id)
+    Tcut = int(eos.max()) + 1
+    out2 = enc.encode_text(ids[:, :Tcut])
+    assert (1 - _cos(out2, ref)).max() < COS_TOL
+
+
+def test_chunking_beyond_max_batch(tiny):
+    enc, W, co = tiny
+    s = co.TINY
+    rng = np.random.Generator(np.random.Philox(8))
+    px = rng.standard_normal((19, 3, s.v_image, s.v_image), dtype=np.float32)  # max_batch_image = 8
+    out = enc.encode_image(px)
+    ref = co.embed_images(px, W, s)
+    assert (1 - _cos(out, ref)).max() < COS_TOL
+    one = enc.encode_image(px[4:5])
+    np.testing.assert_allclose(one[0], out[4], atol=2e-6)  # batch-size invariance
+
+
+def test_u8_fused_preprocess_matches_float_path(tiny):
+    enc, W, co = tiny
+    s = co.TINY
+    rng = np.random.Generator(np.random.Philox(9))
+    u8 = rng.integers(0, 256, size=(4, s.v_image, s.v_image, 3), dtype=np.uint8)
+    a = enc.encode_image(u8)
+    b = enc.encode_image(co.normalize_u8(u8))
+    assert (1 - _cos(a, b)).max() < 1e-5
+    assert (1 - _cos(a, co.embed_images(co.normalize_u8(u8), W, s))).max() < COS_TOL
+
+
+def test_device_tensor_io(tiny):
+    import torch
+
+    enc, W, co = tiny
+    s = co.TINY
+    rng = np.random.Generator(np.random.Philox(10))
+    px = rng.standard_normal((3, 3, s.v_image, s.v_image), dtype=np.float32)
+    out = enc.encode_image(torch.from_numpy(px).cuda())
+    assert out.is_cuda
+    ref = enc.encode_image(px)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-6)
+
+
+def test_errors_are_loud(tiny):
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+
+    enc, W, co = tiny
+    with pytest.raises(ValueError):
+        enc.encode_image(np.zeros((1, 3, 32, 32), np.float32))
+    with pytest.raises(RuntimeError):
+        enc.encode_text(np.zeros((1, co.TINY.t_ctx + 1), np.int32))
+    fresh = ClipEncoder(ClipShape.from_any(co.TINY), max_batch_image=2, max_batch_text=2)
+    with pytest.raises(RuntimeError):  # weights missing -> finalize fails
+        fresh.load_state_dict({k: v for k, v in list(W.items())[:10]})
+
+
+@pytest.fixture(scope="module")
+def b32():
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    W = co.init_weights(co.VIT_B32, seed=0)
+    enc = ClipEncoder(ClipShape.from_any(co.VIT_B32), max_batch_image=16, max_batch_text=16)
+    enc.load_state_dict(W)
+    return enc, W, co
+
+
+def test_b32_image_and_text_embeddings(b32):
+    enc, W, co = b32
+    s = co.VIT_B32
+    rng = np.random.Generator(np.random.Philox(1))
+    px = rng.standard_normal((6, 3, 224, 224), dtype=np.float32)
+    out = enc.encode_image(px)
+    ref = co.embed_images(px, W, s)
+    assert (1 - _cos(out, ref)).max() < COS_TOL
+    ids = co.synthetic_text_ids(6, 77, s.t_vocab, s.eos_token_id, seed=2, bos=49406)
+    out_t = enc.encode_text(ids)
+    ref_t = co.embed_texts(ids, W, s)
+    assert (1 - _cos(out_t, ref_t)).max() < COS_TOL

@@ -1,0 +1,213 @@
+"""Flat cosine index on the MI355X vs oracle/retrieval_oracle.py: ids (labels) and ranking bit-exact,
+distances bit-exact (same canonical fp64 arithmetic), across storage dtypes, batch sizes, k regimes
+(fused top-k, paged top-k), ties, mutation and edge cases."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.index import FlatIndex, blend, merge_topk
+    from oracle import retrieval_oracle as ro
+
+    return FlatIndex, blend, merge_topk, ro
+
+
+def _corpus(n, d, seed):
+    rng = np.random.Generator(np.random.Philox(seed))
+    return rng.standard_normal((n, d), dtype=np.float32)
+
+
+def _check(idx, ro, stored, labels, q, k):
+    lab, dist, cnt = idx.query(q, k)
+    ol, od, oc = ro.query(q, stored, labels, k)
+    np.testing.assert_array_equal(cnt, oc)
+    np.testing.assert_array_equal(lab, ol)
+    np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("N,D", [(1, 128), (15, 128), (1000, 128), (5000, 512), (20011, 768)])
+def test_query_matches_oracle(mods, dtype, N, D):
+    FlatIndex, _, _, ro = mods
+    c = _corpus(N, D, seed=N + D)
+    labels = np.arange(N, dtype=np.int64) * 3 + 5
+    idx = FlatIndex(D, dtype)
+    idx.add(c, labels)
+    assert idx.count() == N
+    stored = ro.normalize_rows(c, dtype)
+    np.testing.assert_array_equal(idx.get(labels[: min(N, 64)]), stored[: min(N, 64)].astype(np.float32))
+    for Q, k in [(1, 1), (1, 10), (3, 10), (17, 10), (40, 5), (2, 24), (70, 10)]:
+        q = _corpus(Q, D, seed=1000 + Q + k)
+        _check(idx, ro, stored, labels, q, k)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_large_k_paging_and_k_beyond_count(mods, dtype):
+    FlatIndex, _, _, ro = mods
+    N, D = 3000, 128
+    c = _corpus(N, D, seed=11)
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(D, dtype)
+    idx.add(c, labels)
+    stored = ro.normalize_rows(c, dtype)
+    q = _corpus(3, D, seed=12)
+    for k in (25, 100, 1000):
+        _check(idx, ro, stored, labels, q, k)
+    small = FlatIndex(D, dtype)
+    small.add(c[:6], labels[:6])
+    # the UI's "All" asks for 1000 results of a 6-image collection (main.py:757): not an error
+    _check(small, ro, stored[:6], labels[:6], q, 1000)
+    _check(small, ro, stored[:6], labels[:6], q[:1], 10)
+
+
+def test_ties_break_by_label_and_duplicates(mods):
+    FlatIndex, _, _, ro = mods
+    D = 128
+    base = _corpus(40, D, seed=21)
+    c = np.concatenate([base, base, base[:10], base])  # exact duplicates -> exactly equal distances
+    N = c.shape[0]
+    labels = np.arange(N, dtype=np.int64) + 100
+    for dtype in ("f32", "f16"):
+        idx = FlatIndex(D, dtype)
+        idx.add(c, labels)
+        stored = ro.normalize_rows(c, dtype)
+        q = base[:5] + 0.01 * _corpus(5, D, seed=22)
+        for k in (1, 3, 10, 24, 60):
+            _check(idx, ro, stored, labels, q, k)
+    # every row identical: the k smallest labels win
+    same = np.tile(base[:1], (500, 1))
+    idx = FlatIndex(D, "f32")
+    idx.add(same, np.arange(500, dtype=np.int64))
+    lab, dist, cnt = idx.query(base[:1], 10)
+    np.testing.assert_array_equal(lab[0], np.arange(10))
+
+
+def test_adversarial_order_ascending_similarity(mods):
+    """Rows sorted so every later row beats all earlier ones: the running top-k' list is rewritten constantly."""
+    FlatIndex, _, _, ro = mods
+    N, D = 6000, 128
+    c = _corpus(N, D, seed=31)
+    q = _corpus(1, D, seed=32)
+    sims = (c / np.linalg.norm(c, axis=1, keepdims=True)) @ (q[0] / np.linalg.norm(q[0]))
+    c = c[np.argsort(sims)]
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    _check(idx, ro, ro.normalize_rows(c, "f16"), labels, q, 10)
+
+
+def test_incremental_add_remove_update(mods):
+    FlatIndex, _, _, ro = mods
+    D = 128
+    c = _corpus(900, D, seed=41)
+    labels = np.arange(900, dtype=np.int64)
+    idx = FlatIndex(D, "f32")
+    for r0 in range(0, 900, 250):
+        idx.add(c[r0:r0 + 250], labels[r0:r0 + 250])
+    q = _corpus(4, D, seed=42)
+    stored = ro.normalize_rows(c, "f32")
+    _check(idx, ro, stored, labels, q, 10)
+    # labels must keep increasing (they are the tie-break order)
+    with pytest.raises(RuntimeError):
+        idx.add(c[:1], np.array([5], dtype=np.int64))
+    drop = np.array([0, 17, 450, 899, 12345], dtype=np.int64)
+    assert idx.remove(drop) == 4
+    keep = np.setdiff1d(labels, drop)
+    assert idx.count() == keep.shape[0]
+    np.testing.assert_array_equal(idx.labels(), keep)
+    _check(idx, ro, stored[keep], keep, q, 10)
+    newv = _corpus(2, D, seed=43)
+    idx.update(np.array([3, 600], dtype=np.int64), newv)
+    c2 = c.copy()
+    c2[3], c2[600] = newv[0], newv[1]
+    _check(idx, ro, ro.normalize_rows(c2, "f32")[keep], keep, q, 10)
+    idx.clear()
+    assert idx.count() == 0
+
+
+def test_empty_index_and_errors(mods):
+    FlatIndex, _, _, ro = mods
+    idx = FlatIndex(128, "f32")
+    lab, dist, cnt = idx.query(_corpus(2, 128, seed=1), 5)
+    assert (lab == -1).all() and np.isinf(dist).all() and (cnt == 0).all()
+    with pytest.raises(RuntimeError):
+        FlatIndex(100, "f32")  # dim must be a multiple of 128
+    with pytest.raises(ValueError):
+        idx.add(np.zeros((2, 64), np.float32), np.arange(2))
+
+
+def test_device_tensors_in_and_out(mods):
+    import torch
+
+    FlatIndex, _, _, ro = mods
+    N, D = 2048, 512
+    c = _corpus(N, D, seed=51)
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(D, "f16")
+    idx.add(torch.from_numpy(c).cuda(), labels)
+    q = _corpus(9, D, seed=52)
+    lab, dist, cnt = idx.query(torch.from_numpy(q).cuda(), 10)
+    assert lab.is_cuda and dist.is_cuda
+    ol, od, oc = ro.query(q, ro.normalize_rows(c, "f16"), labels, 10)
+    np.testing.assert_array_equal(lab.cpu().numpy(), ol)
+    np.testing.assert_array_equal(dist.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_save_load_roundtrip(mods, tmp_path):
+    FlatIndex, _, _, ro = mods
+    N, D = 700, 128
+    c = _corpus(N, D, seed=61)
+    labels = np.arange(N, dtype=np.int64) * 2
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    p = tmp_path / "shard.mmiss"
+    idx.save(str(p))
+    again = FlatIndex(D, "f16")
+    again.load(str(p))
+    assert again.count() == N
+    q = _corpus(3, D, seed=62)
+    a = idx.query(q, 10)
+    b = again.query(q, 10)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    wrong = FlatIndex(D, "f32")
+    with pytest.raises(RuntimeError):
+        wrong.load(str(p))
+
+
+def test_blend_matches_oracle_and_reference_formula(mods):
+    from oracle import clip_oracle as co
+
+    _, blend, _, ro = mods
+    img = _corpus(33, 512, seed=71)
+    txt = _corpus(33, 512, seed=72)
+    for w in (0.5, 0.3, 0.0, 1.0, 1.7):  # the backend does not clamp weight_image (main.py:299)
+        out = blend(img, txt, w)
+        np.testing.assert_array_equal(out.view(np.uint32), ro.blend(img, txt, w).view(np.uint32))
+        # numpy's own float32 evaluation of main.py:852-860 differs only in the last bits
+        np.testing.assert_allclose(out, co.blend_reference(img, txt, w), rtol=0, atol=1e-6)
+
+
+def test_merge_topk_equals_unsharded(mods):
+    FlatIndex, _, merge_topk, ro = mods
+    N, D, S, k = 4000, 128, 4, 10
+    c = _corpus(N, D, seed=81)
+    labels = np.arange(N, dtype=np.int64)
+    q = _corpus(6, D, seed=82)
+    per = N // S
+    ds, ls = [], []
+    for s in range(S):
+        sh = FlatIndex(D, "f16")
+        sh.add(c[s * per:(s + 1) * per], labels[s * per:(s + 1) * per])
+        l, d, _ = sh.query(q, k)
+        ds.append(d)
+        ls.append(l)
+    ml, md, mc = merge_topk(np.stack(ds), np.stack(ls))
+    ol, od, oc = ro.query(q, ro.normalize_rows(c, "f16"), labels, k)
+    np.testing.assert_array_equal(ml, ol)
+    np.testing.assert_array_equal(md.view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(mc, oc)

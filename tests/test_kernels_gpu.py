@@ -1,0 +1,180 @@
+"""Kernel-level parity on the MI355X: each hand-written HIP kernel against a plain fp32 restatement of the
+same op (tolerances written next to each check). Calls go through the C-ABI (include/mmiss_debug.h)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    import torch
+
+    return t.to(torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd import _lib
+
+    lib = _lib.load()
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch, _lib, lib
+
+
+def _gemm(env, epi, A, W, out, bias=None, aux=None, p0=0, p1=0):
+    torch, _lib, lib = env
+    M, K = A.shape
+    N = W.shape[0]
+    _lib.check(lib.mmiss_dbg_gemm(0, None, epi, 0, A.data_ptr(), W.data_ptr(), out.data_ptr(),
+                                  bias.data_ptr() if bias is not None else None,
+                                  aux.data_ptr() if aux is not None else None, M, N, K, p0, p1))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (384, 768, 768), (1280, 2304, 768), (256, 768, 3072)])
+def test_gemm_f32_epilogue(env, M, N, K):
+    torch, _lib, lib = env
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _gemm(env, _lib.EPI_F32, A, W, out)
+    ref = A.float() @ W.float().T
+    # bf16 products are exact in fp32; only the accumulation order differs: 1e-4 relative to the row scale
+    err = (out - ref).abs().max().item()
+    assert err <= 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_asymmetric_layout(env):
+    """A = identity-like, asymmetric W: catches a transposed or permuted C write (guide §3)."""
+    torch, _lib, lib = env
+    M = N = 128
+    K = 128
+    A = torch.zeros(M, K, device="cuda")
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    W = (torch.arange(N * K, device="cuda", dtype=torch.float32).reshape(N, K) % 251) / 16.0
+    out = torch.zeros(M, N, device="cuda")
+    _gemm(env, _lib.EPI_F32, _bf16(A), _bf16(W), out)
+    ref = _bf16(A).float() @ _bf16(W).float().T
+    assert torch.equal(out, ref)
+
+
+def test_gemm_bias_bf16_and_qgelu(env):
+    torch, _lib, lib = env
+    M, N, K = 256, 512, 256
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().T + bias
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    _gemm(env, _lib.EPI_BIAS_BF16, A, W, out, bias=bias)
+    # output rounded to bf16: half an ulp = 2^-9 relative
+    assert torch.allclose(out.float(), ref, rtol=2 ** -8, atol=1e-3)
+    out2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, out2, bias=bias)
+    ref2 = ref * torch.sigmoid(1.702 * ref)
+    assert torch.allclose(out2.float(), ref2, rtol=2 ** -7, atol=2e-3)
+
+
+def test_gemm_residual_and_patch(env):
+    torch, _lib, lib = env
+    M, N, K = 256, 256, 192
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    x = x0.clone()
+    _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias)
+    ref = x0 + A.float() @ W.float().T + bias
+    assert torch.allclose(x, ref, rtol=1e-5, atol=2e-4)
+    # patch epilogue: G = 4 patches per image, T = 5 tokens; rows land at img*T + 1 + patch, + pos[1 + patch]
+    G, T = 4, 5
+    imgs = M // G
+    pos = torch.randn(T, N, device="cuda", generator=g)
+    out = torch.zeros(imgs * T, N, device="cuda")
+    _gemm(env, _lib.EPI_PATCH_F32, A, W, out, aux=pos, p0=G, p1=T)
+    acc = (A.float() @ W.float().T).reshape(imgs, G, N) + pos[1:][None]
+    assert torch.allclose(out.reshape(imgs, T, N)[:, 1:], acc, rtol=1e-5, atol=2e-4)
+    assert torch.equal(out.reshape(imgs, T, N)[:, 0], torch.zeros(imgs, N, device="cuda"))
+
+
+@pytest.mark.parametrize("d", [128, 512, 768, 1024])
+def test_layernorm(env, d):
+    torch, _lib, lib = env
+    M = 333
+    g = torch.Generator(device="cuda").manual_seed(d)
+    x = torch.randn(M, d, device="cuda", generator=g) * 3 + 0.5
+    gam = torch.randn(d, device="cuda", generator=g)
+    bet = torch.randn(d, device="cuda", generator=g)
+    ref = torch.nn.functional.layer_norm(x, (d,), gam, bet, 1e-5)
+    out = torch.zeros(M, d, device="cuda")
+    _lib.check(lib.mmiss_dbg_layernorm(0, None, x.data_ptr(), gam.data_ptr(), bet.data_ptr(), out.data_ptr(), 0, M, d, 1e-5))
+    torch.cuda.synchronize()
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    outb = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mmiss_dbg_layernorm(0, None, x.data_ptr(), gam.data_ptr(), bet.data_ptr(), outb.data_ptr(), 1, M, d, 1e-5))
+    torch.cuda.synchronize()
+    assert torch.allclose(outb.float(), ref, rtol=2 ** -8, atol=1e-3)
+
+
+def _attn_ref(torch, qkv, B, T, H, causal):
+    d = H * 64
+    x = qkv.float().reshape(B, T, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.triu(torch.full((T, T), float("-inf"), device=qkv.device), diagonal=1)
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).transpose(1, 2).reshape(B * T, d)
+
+
+@pytest.mark.parametrize("B,T,H,causal", [(3, 50, 12, 0), (2, 77, 8, 1), (2, 16, 2, 1), (1, 5, 2, 0), (2, 257, 4, 0), (1, 248, 3, 1), (5, 33, 2, 1)])
+def test_attention(env, B, T, H, causal):
+    torch, _lib, lib = env
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
+    qkv = _bf16(torch.randn(B * T, 3 * H * 64, device="cuda", generator=g))
+    ctx = torch.zeros(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mmiss_dbg_attention(0, None, qkv.data_ptr(), ctx.data_ptr(), B, T, H, causal))
+    torch.cuda.synchronize()
+    ref = _attn_ref(torch, qkv, B, T, H, bool(causal))
+    # P and the output are rounded to bf16 (2^-9 relative each); values are O(1)
+    err = (ctx.float() - ref).abs().max().item()
+    assert err < 2e-2, err
+    assert torch.isfinite(ctx.float()).all()
+
+
+def test_attention_peaked_softmax(env):
+    """One key dominating every query (large logits): the max-subtraction path must not overflow."""
+    torch, _lib, lib = env
+    B, T, H = 1, 50, 1
+    qkv = torch.zeros(B * T, 3 * 64, device="cuda")
+    qkv[:, 0:64] = 4.0          # q
+    qkv[7, 64:128] = 6.0        # key 7 has a huge dot with every q
+    qkv[:, 128:192] = torch.arange(T, device="cuda", dtype=torch.float32)[:, None] / 8.0  # v
+    qkv = _bf16(qkv)
+    ctx = torch.zeros(B * T, 64, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mmiss_dbg_attention(0, None, qkv.data_ptr(), ctx.data_ptr(), B, T, H, 0))
+    torch.cuda.synchronize()
+    ref = _attn_ref(torch, qkv, B, T, H, False)
+    assert torch.allclose(ctx.float(), ref, atol=1e-2)
+
+
+@pytest.mark.parametrize("S,P", [(224, 32), (64, 32), (224, 14)])
+def test_im2col(env, S, P):
+    torch, _lib, lib = env
+    B = 3
+    G = S // P
+    Kreal = 3 * P * P
+    Kp = (Kreal + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(S + P)
+    px = torch.randn(B, 3, S, S, device="cuda", generator=g)
+    out = torch.full((B * G * G, Kp), 7.0, device="cuda").to(torch.bfloat16)
+    _lib.check(lib.mmiss_dbg_im2col(0, None, px.data_ptr(), out.data_ptr(), B, S, P, Kp))
+    torch.cuda.synchronize()
+    ref = px.reshape(B, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, Kreal).to(torch.bfloat16)
+    assert torch.equal(out[:, :Kreal], ref)
+    assert torch.equal(out[:, Kreal:].float(), torch.zeros(B * G * G, Kp - Kreal, device="cuda"))
