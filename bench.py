@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the embed-and-retrieve hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): CLIP ViT-B/32 image encode at batch 256 on synthetic, already
+CLIP-normalised 224x224 pixels resident in HBM, random-init weights (seed 0), each embedding then queried
+top-10 (cosine) against a 100k x 512 flat index. One step = one batch of 256 images through
+patchify -> 12 layers -> pool -> project -> L2-normalise -> index query; `value` = images/s over all ranks.
+
+N > 1 (weak scaling, one process per GPU, RCCL): every rank encodes its own 256 images (no collective),
+holds its own 100k-row shard (labels are global), all-gathers the [256,512] embeddings so every rank
+searches all N*256 queries in its shard, all-gathers the per-shard top-10 and merges (X1).
+
+Second half of BASELINE.json's metric, reported in the same JSON line under "retrieval": cosine top-10
+over a 10M x 512 fp16 index (row-sharded over the ranks) at Q=1 (HBM-bound scan) and Q=1024.
+
+The JSON line also carries `roofline` (dominant kernel class by device time, HIP events recorded by
+libmmiss on the stream the kernels run on, inside the timed region) and `cpu_baseline` (the numpy oracle
+= a port of the reference's CPU arithmetic, on a bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0           # spec; ~6.3 TB/s achievable (same guide)
+
+KERNEL_SYMBOL = {  # libmmiss kernel class -> symbol as rocprofv3 --kernel-trace prints it
+    "gemm_bf16_f32": "gemm_bf16_128x128<0>", "gemm_bf16_bias": "gemm_bf16_128x128<1>",
+    "gemm_bf16_bias_qgelu": "gemm_bf16_128x128<2>", "gemm_bf16_bias_resid": "gemm_bf16_128x128<3>",
+    "gemm_bf16_patch": "gemm_bf16_128x128<4>", "attention": "attention_kernel<2,false>",
+    "layernorm": "layernorm_kernel<true>", "im2col": "im2col_kernel<false>",
+    "scan_topk_f16": "scan_topk_kernel<_Float16,...>", "scan_topk_f32": "scan_topk_kernel<float,...>",
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--index-rows", type=int, default=100_000, help="rows per rank of the step's index")
+    ap.add_argument("--retrieval-rows", type=int, default=10_000_000, help="total rows of the 10M x 512 f16 scan benchmark (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd import _lib
+    from mmiss_amd.encoder import ClipEncoder, VIT_B32, random_state_dict
+    from mmiss_amd.index import FlatIndex, merge_topk
+
+    B, D, K_TOP = args.batch, VIT_B32.proj_dim, 10
+    W = random_state_dict(VIT_B32, seed=0)
+    enc = ClipEncoder(VIT_B32, device=local_rank, max_batch_image=B, max_batch_text=B)
+    enc.load_state_dict(W)
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pixels = torch.randn(B, 3, 224, 224, device=dev, generator=gen)  # resident in HBM before the timed region
+    index = FlatIndex(D, "f16", device=local_rank, capacity=args.index_rows)
+    rows = torch.randn(args.index_rows, D, device=dev, generator=gen)
+    index.add(rows, np.arange(rank * args.index_rows, (rank + 1) * args.index_rows, dtype=np.int64))
+    del rows
+    emb = torch.empty(B, D, device=dev)
+    emb_all = torch.empty(world * B, D, device=dev) if world > 1 else emb
+
+    def step():
+        enc.encode_image(pixels, out=emb)
+        if world > 1:
+            dist.all_gather_into_tensor(emb_all, emb)
+            lab, dst, _ = index.query(emb_all, K_TOP)
+            lab_all = torch.empty((world,) + tuple(lab.shape), dtype=lab.dtype, device=dev)
+            dst_all = torch.empty((world,) + tuple(dst.shape), dtype=dst.dtype, device=dev)
+            dist.all_gather_into_tensor(lab_all, lab)
+            dist.all_gather_into_tensor(dst_all, dst)
+            return merge_topk(dst_all, lab_all)
+        return index.query(emb, K_TOP)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.prof_reset()
+    _lib.prof_enable(not args.no_kernel_events)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    prof = _lib.prof_read()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * B * args.steps / elapsed
+
+    # ---------------------------------------------------------------- roofline of the dominant kernel class
+    roofline = None
+    kernels = []
+    if prof:
+        tot_ms = sum(p["ms"] for p in prof)
+        for p in sorted(prof, key=lambda p: -p["ms"]):
+            kernels.append({"kernel": p["kernel"], "launches": p["launches"], "avg_us": round(1e3 * p["ms"] / p["launches"], 2),
+                            "share": round(p["ms"] / tot_ms, 4),
+                            "tflops": round(p["flops"] / p["ms"] / 1e9, 1) if p["flops"] else None,
+                            "gbs": round(p["bytes"] / p["ms"] / 1e6, 1)})
+        top = max(prof, key=lambda p: p["ms"])
+        achieved = top["flops"] / top["ms"] / 1e9  # TFLOP/s: algorithmic flops per launch / mean launch duration
+        roofline = {"bound": "mfma", "kernel": top["kernel"], "symbol": KERNEL_SYMBOL.get(top["kernel"], top["kernel"]),
+                    "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": top["launches"], "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
+                    "flops_per_launch": top["flops"] / top["launches"]}
+
+    # ---------------------------------------------------------------- 10M x 512 f16 scan (second half of the metric)
+    retrieval = None
+    if args.retrieval_rows > 0:
+        retrieval = bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib)
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(W, D, args.index_rows, K_TOP)
+
+    if rank == 0:
+        out = {
+            "metric": "images/s CLIP-B/32 encode @ bs256; Mvec/s cosine top-10 over 10M x 512",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ViT-B/32 image encode bs=256 per GPU + cosine top-10 of every embedding vs a "
+                                   f"{args.index_rows}x512 f16 flat index per GPU (BASELINE configs[1])",
+                       "global_batch": world * B, "image": "3x224x224 f32 resident in HBM", "weights": "random-init seed 0",
+                       "index_dtype": "f16", "k": K_TOP, "parallelism": f"dp{world}",
+                       "flops_per_image": 8.818e9, "kernel_events_in_timed_region": not args.no_kernel_events},
+            "encode_tflops": round(value * 8.818e9 / 1e12 / world, 1),
+            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib):
+    """cosine top-10 over N x 512 f16 rows sharded over the ranks; Q=1 (HBM-bound) and Q=1024."""
+    N, D, K_TOP = args.retrieval_rows, 512, 10
+    per = N // world
+    idx = FlatIndex(D, "f16", device=local_rank, capacity=per)
+    gen = torch.Generator(device=dev).manual_seed(4 + rank)
+    chunk = 1_000_000
+    for r0 in range(0, per, chunk):
+        n = min(chunk, per - r0)
+        idx.add(torch.randn(n, D, device=dev, generator=gen), np.arange(rank * per + r0, rank * per + r0 + n, dtype=np.int64))
+    res = {"rows": N, "rows_per_gpu": per, "dim": D, "dtype": "f16", "k": K_TOP}
+    for Q, iters in ((1, 20), (16, 10), (1024, 3)):
+        q = torch.randn(Q, D, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+
+        def run():
+            lab, dst, _ = idx.query(q, K_TOP)
+            if world > 1:
+                lab_all = torch.empty((world,) + tuple(lab.shape), dtype=lab.dtype, device=dev)
+                dst_all = torch.empty((world,) + tuple(dst.shape), dtype=dst.dtype, device=dev)
+                dist.all_gather_into_tensor(lab_all, lab)
+                dist.all_gather_into_tensor(dst_all, dst)
+                return merge_topk(dst_all, lab_all)
+            return lab, dst
+
+        run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / iters
+        _lib.prof_enable(False)
+        prof = {p["kernel"]: p for p in _lib.prof_read()}
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        scan = prof.get("scan_topk_f16")
+        entry = {"ms_per_batch": round(dt * 1e3, 3), "mvec_per_s": round(N / dt / 1e6, 1),
+                 "gpairs_per_s": round(Q * N / dt / 1e9, 2)}
+        if scan:
+            scan_ms = scan["ms"] / scan["launches"]
+            gbs = per * D * 2 / scan_ms / 1e6
+            tfl = 2.0 * Q * per * D / scan_ms / 1e9
+            entry["scan_kernel"] = {"avg_ms": round(scan_ms, 4), "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                                    "tflops": round(tfl, 1), "mfma_frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4)}
+            other = sum(p["ms"] / iters for k, p in prof.items() if k != "scan_topk_f16")
+            entry["other_kernels_ms"] = round(other, 4)
+        res[f"Q{Q}"] = entry
+    res["headline_mvec_per_s"] = res["Q1"]["mvec_per_s"]
+    idx.close()
+    return res
+
+
+def cpu_baseline(W, D, index_rows, k):
+    """The numpy oracle (a port of the reference's CPU fp32 path: HF CLIP forward + exact cosine top-k) on a
+    bounded sample of the same workload: 32 images encoded at bs=32 and 8 queries against the 100k x 512 index."""
+    import numpy as np
+    from oracle import clip_oracle as co
+    from oracle import retrieval_oracle as ro
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rng = np.random.Generator(np.random.Philox(99))
+    px = rng.standard_normal((32, 3, 224, 224), dtype=np.float32)
+    co.embed_images(px[:4], W, co.VIT_B32)  # warm-up
+    t0 = time.perf_counter()
+    emb = co.embed_images(px, W, co.VIT_B32)
+    t_img = (time.perf_counter() - t0) / 32
+    corpus = rng.standard_normal((index_rows, D), dtype=np.float32)
+    stored = ro.normalize_rows(corpus, "f16")
+    labels = np.arange(index_rows, dtype=np.int64)
+    t0 = time.perf_counter()
+    ro.query(emb[:8], stored, labels, k)
+    t_q = (time.perf_counter() - t0) / 8
+    return {"value": round(1.0 / (t_img + t_q), 2), "unit": "images/s", "cores": int(threads), "kind": "port",
+            "sample": f"numpy fp32 oracle: 32 images at bs=32 ({t_img*1e3:.1f} ms/img) + exact fp64 cosine top-{k} of 8 "
+                      f"queries vs {index_rows}x{D} ({t_q*1e3:.1f} ms/query); host has {os.cpu_count()} logical CPUs",
+            "encode_only_images_per_s": round(1.0 / t_img, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -88,8 +88,13 @@ int mmiss_encoder_destroy(mmiss_encoder* enc);
 int mmiss_encoder_set_weight(mmiss_encoder* enc, const char* hf_key, const float* data, int64_t numel, int* used);
 /* checks that every tensor of both towers was supplied; must precede encode calls */
 int mmiss_encoder_finalize(mmiss_encoder* enc);
-/* run on a caller stream (a hipStream_t passed as void*); NULL = the handle's own stream */
-int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream);
+/*
+ * use_own != 0 (the default after create): calls run on the handle's private stream and return after the
+ * work has finished (host-synchronous). use_own == 0: calls are enqueued on the caller's hipStream_t
+ * (passed as void*; NULL = the legacy default stream) and return without synchronising unless an
+ * input or output lives in host memory.
+ */
+int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream, int32_t use_own);
 
 /*
  * pixels: float32 [B,3,S,S] NCHW, already CLIP-normalised (the output of CLIPImageProcessor,
@@ -130,7 +135,8 @@ int mmiss_encoder_tap(mmiss_encoder* enc, int tower, int what, float* out, int64
  */
 int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device, int64_t capacity_hint, mmiss_index** out);
 int mmiss_index_destroy(mmiss_index* idx);
-int mmiss_index_set_stream(mmiss_index* idx, void* hip_stream);
+/* same contract as mmiss_encoder_set_stream */
+int mmiss_index_set_stream(mmiss_index* idx, void* hip_stream, int32_t use_own);
 
 /*
  * vecs: float32 [n,dim] (any norm > 0). labels: int64 [n], strictly increasing and greater than every

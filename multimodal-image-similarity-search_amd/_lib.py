@@ -56,14 +56,14 @@ SIGNATURES = {
     "mmiss_encoder_destroy": (_I, [_P]),
     "mmiss_encoder_set_weight": (_I, [_P, C.c_char_p, _P, _I64, C.POINTER(_I)]),
     "mmiss_encoder_finalize": (_I, [_P]),
-    "mmiss_encoder_set_stream": (_I, [_P, _P]),
+    "mmiss_encoder_set_stream": (_I, [_P, _P, _I32]),
     "mmiss_encode_image": (_I, [_P, _P, _I32, _P]),
     "mmiss_encode_image_u8": (_I, [_P, _P, _I32, _P]),
     "mmiss_encode_text": (_I, [_P, _P, _I32, _I32, _P]),
     "mmiss_encoder_tap": (_I, [_P, _I, _I, _P, _I64, C.POINTER(_I64)]),
     "mmiss_index_create": (_I, [_I32, _I32, _I, _I64, C.POINTER(_P)]),
     "mmiss_index_destroy": (_I, [_P]),
-    "mmiss_index_set_stream": (_I, [_P, _P]),
+    "mmiss_index_set_stream": (_I, [_P, _P, _I32]),
     "mmiss_index_add": (_I, [_P, _P, _P, _I64]),
     "mmiss_index_update": (_I, [_P, _P, _P, _I64]),
     "mmiss_index_remove": (_I, [_P, _P, _I64, C.POINTER(_I64)]),

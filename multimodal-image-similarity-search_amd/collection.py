@@ -1,0 +1,302 @@
+"""FlatCollection — the chromadb Collection surface the reference uses, over the in-HBM FlatIndex.
+
+Call sites mirrored (paths relative to the reference root):
+  client.create_collection(name, metadata={"hnsw:space": "cosine"})     backend/app/utils.py:127-130
+  collection.add(ids, embeddings, metadatas, documents)                  backend/app/main.py:735-740
+  collection.query(query_embeddings, n_results, include)                 backend/app/main.py:761-765
+  collection.get(ids=..., include=[...]) / get(include=[])               backend/app/main.py:533,556,563-566,631-634
+  collection.update(ids, metadatas)                                      backend/app/main.py:503-510,1030-1033
+  collection.delete(ids)                                                 backend/app/main.py:1065-1069
+  collection.count()                                                     init_db.py:58
+
+Only the embedding arithmetic runs on the GPU (FlatIndex); ids, metadatas and documents are host-side
+bookkeeping exactly as they are bookkeeping inside chromadb's sqlite. String ids map to int64 labels
+handed out in insertion order; labels are the deterministic tie-break of equal distances.
+"""
+from __future__ import annotations
+
+import json
+import os
+import threading
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .index import FlatIndex
+
+
+class DuplicateIDError(ValueError):
+    """Same condition chromadb reports for add() of an id that already exists."""
+
+
+def _as_list(x):
+    if x is None:
+        return None
+    if isinstance(x, (str, bytes)):
+        return [x]
+    return list(x)
+
+
+class FlatCollection:
+    def __init__(self, name: str = "image-match", dim: Optional[int] = None, dtype: str = "f32", device: int = 0,
+                 metadata: Optional[dict] = None, persist_dir: Optional[str] = None, autosave: bool = True):
+        self.name = name
+        self.metadata = dict(metadata or {"hnsw:space": "cosine"})
+        space = self.metadata.get("hnsw:space", "cosine")
+        if space != "cosine":
+            raise ValueError(f"FlatCollection implements the cosine space only (got {space!r})")
+        self._dim = dim
+        self._dtype = dtype
+        self._device = device
+        self._index: Optional[FlatIndex] = None
+        self._ids: List[str] = []              # row order == label order
+        self._labels: List[int] = []
+        self._by_id: Dict[str, int] = {}       # id -> label
+        self._meta: Dict[int, Optional[dict]] = {}
+        self._docs: Dict[int, Optional[str]] = {}
+        self._next_label = 0
+        self._lock = threading.RLock()         # 1 writer + readers (the reference has a background updater, main.py:410)
+        self._persist_dir = persist_dir
+        self._autosave = autosave
+        if persist_dir:
+            os.makedirs(persist_dir, exist_ok=True)
+            if os.path.exists(self._meta_path()):
+                self._load()
+
+    # ------------------------------------------------------------------ persistence (replaces chroma_data/)
+    def _meta_path(self):
+        return os.path.join(self._persist_dir, f"{self.name}.meta.json")
+
+    def _index_path(self):
+        return os.path.join(self._persist_dir, f"{self.name}.index.mmiss")
+
+    def persist(self) -> None:
+        if not self._persist_dir:
+            return
+        with self._lock:
+            blob = {
+                "name": self.name, "metadata": self.metadata, "dim": self._dim, "dtype": self._dtype,
+                "next_label": self._next_label, "ids": self._ids, "labels": self._labels,
+                "metadatas": [self._meta.get(l) for l in self._labels],
+                "documents": [self._docs.get(l) for l in self._labels],
+            }
+            tmp = self._meta_path() + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(blob, f)
+            if self._index is not None:
+                self._index.save(self._index_path())
+            os.replace(tmp, self._meta_path())
+
+    def _load(self) -> None:
+        with open(self._meta_path()) as f:
+            blob = json.load(f)
+        self.metadata = blob.get("metadata", self.metadata)
+        self._dim = blob["dim"]
+        self._dtype = blob.get("dtype", self._dtype)
+        self._next_label = blob["next_label"]
+        self._ids = list(blob["ids"])
+        self._labels = [int(x) for x in blob["labels"]]
+        self._by_id = dict(zip(self._ids, self._labels))
+        self._meta = dict(zip(self._labels, blob["metadatas"]))
+        self._docs = dict(zip(self._labels, blob["documents"]))
+        if self._dim is not None and self._labels:
+            self._ensure_index(self._dim)
+            self._index.load(self._index_path())
+            if self._index.count() != len(self._labels):
+                raise RuntimeError("collection files are inconsistent (row count differs from id count)")
+
+    def _saved(self):
+        if self._autosave:
+            self.persist()
+
+    # ------------------------------------------------------------------ helpers
+    def _ensure_index(self, dim: int) -> FlatIndex:
+        if self._index is None:
+            self._dim = int(dim)
+            self._index = FlatIndex(self._dim, self._dtype, self._device)
+        elif dim != self._dim:
+            raise ValueError(f"embedding dimension {dim} does not match the collection's {self._dim}")
+        return self._index
+
+    @staticmethod
+    def _embeddings_array(embeddings) -> np.ndarray:
+        arr = np.asarray(embeddings, dtype=np.float32)
+        if arr.ndim == 1:
+            arr = arr[None]
+        if arr.ndim != 2:
+            raise ValueError("embeddings must be a list of vectors")
+        return np.ascontiguousarray(arr)
+
+    # ------------------------------------------------------------------ chroma surface
+    def count(self) -> int:
+        with self._lock:
+            return len(self._ids)
+
+    def add(self, ids, embeddings, metadatas=None, documents=None) -> None:
+        ids = _as_list(ids)
+        emb = self._embeddings_array(embeddings)  # the reference passes python lists of floats (main.py:687)
+        metadatas = _as_list(metadatas) if metadatas is not None else [None] * len(ids)
+        documents = _as_list(documents) if documents is not None else [None] * len(ids)
+        if not (len(ids) == emb.shape[0] == len(metadatas) == len(documents)):
+            raise ValueError("ids, embeddings, metadatas and documents differ in length")
+        with self._lock:
+            if len(set(ids)) != len(ids):
+                raise DuplicateIDError("duplicate ids in add()")
+            dup = [i for i in ids if i in self._by_id]
+            if dup:
+                raise DuplicateIDError(f"ids already in collection: {dup[:3]}")
+            index = self._ensure_index(emb.shape[1])
+            labels = np.arange(self._next_label, self._next_label + len(ids), dtype=np.int64)
+            index.add(emb, labels)
+            self._next_label += len(ids)
+            for i, lab in zip(ids, labels.tolist()):
+                self._ids.append(i)
+                self._labels.append(lab)
+                self._by_id[i] = lab
+            for lab, m, d in zip(labels.tolist(), metadatas, documents):
+                self._meta[lab] = dict(m) if m is not None else None
+                self._docs[lab] = d
+            self._saved()
+
+    def query(self, query_embeddings=None, n_results: int = 10, include: Sequence[str] = ("metadatas", "documents", "distances"),
+              **_unused) -> dict:
+        if query_embeddings is None:
+            raise ValueError("FlatCollection.query needs query_embeddings (text embedding functions are out of scope)")
+        q = self._embeddings_array(query_embeddings)
+        include = list(include)
+        with self._lock:
+            Q = q.shape[0]
+            n = len(self._ids)
+            if n == 0 or self._index is None:
+                labs = np.full((Q, 0), -1, dtype=np.int64)
+                dist = np.zeros((Q, 0), dtype=np.float32)
+                cnt = np.zeros((Q,), dtype=np.int32)
+            else:
+                if q.shape[1] != self._dim:
+                    raise ValueError(f"query dimension {q.shape[1]} does not match the collection's {self._dim}")
+                k = max(1, min(int(n_results), n))  # n_results > count is not an error ("All" = 1000, main.py:757)
+                labs, dist, cnt = self._index.query(q, k)
+            label_to_id = dict(zip(self._labels, self._ids))
+            out = {"ids": [], "distances": None, "metadatas": None, "documents": None, "embeddings": None,
+                   "uris": None, "data": None, "included": include}
+            rows = []
+            for qi in range(Q):
+                ls = [int(x) for x in labs[qi, : int(cnt[qi])]]
+                rows.append(ls)
+                out["ids"].append([label_to_id[l] for l in ls])
+            if "distances" in include:
+                out["distances"] = [[float(x) for x in dist[qi, : int(cnt[qi])]] for qi in range(Q)]
+            if "metadatas" in include:
+                out["metadatas"] = [[self._meta.get(l) for l in ls] for ls in rows]
+            if "documents" in include:
+                out["documents"] = [[self._docs.get(l) for l in ls] for ls in rows]
+            if "embeddings" in include:
+                out["embeddings"] = [self._index.get(np.asarray(ls, dtype=np.int64)) for ls in rows]
+            return out
+
+    def get(self, ids=None, include: Sequence[str] = ("metadatas", "documents"), limit: Optional[int] = None,
+            offset: Optional[int] = None, **_unused) -> dict:
+        include = list(include)
+        with self._lock:
+            if ids is None:
+                sel = list(zip(self._ids, self._labels))
+            else:
+                sel = [(i, self._by_id[i]) for i in _as_list(ids) if i in self._by_id]  # missing ids are skipped
+            if offset:
+                sel = sel[int(offset):]
+            if limit is not None:
+                sel = sel[: int(limit)]
+            out = {"ids": [i for i, _ in sel], "metadatas": None, "documents": None, "embeddings": None,
+                   "uris": None, "data": None, "included": include}
+            if "metadatas" in include:
+                out["metadatas"] = [self._meta.get(l) for _, l in sel]
+            if "documents" in include:
+                out["documents"] = [self._docs.get(l) for _, l in sel]
+            if "embeddings" in include:
+                labs = np.asarray([l for _, l in sel], dtype=np.int64)
+                out["embeddings"] = self._index.get(labs) if (self._index is not None and labs.size) else np.zeros((0, self._dim or 0), np.float32)
+            return out
+
+    def update(self, ids, embeddings=None, metadatas=None, documents=None) -> None:
+        ids = _as_list(ids)
+        with self._lock:
+            missing = [i for i in ids if i not in self._by_id]
+            if missing:
+                raise ValueError(f"ids not in collection: {missing[:3]}")
+            labs = [self._by_id[i] for i in ids]
+            if metadatas is not None:
+                for lab, m in zip(labs, _as_list(metadatas)):
+                    if m is not None:
+                        merged = dict(self._meta.get(lab) or {})
+                        merged.update(m)  # chroma merges keys on update
+                        self._meta[lab] = merged
+            if documents is not None:
+                for lab, d in zip(labs, _as_list(documents)):
+                    self._docs[lab] = d
+            if embeddings is not None:
+                self._index.update(np.asarray(labs, dtype=np.int64), self._embeddings_array(embeddings))
+            self._saved()
+
+    def delete(self, ids=None) -> None:
+        with self._lock:
+            if ids is None:
+                ids = list(self._ids)
+            ids = [i for i in _as_list(ids) if i in self._by_id]
+            if not ids:
+                return
+            labs = [self._by_id[i] for i in ids]
+            self._index.remove(np.asarray(labs, dtype=np.int64))
+            gone = set(labs)
+            keep = [(i, l) for i, l in zip(self._ids, self._labels) if l not in gone]
+            self._ids = [i for i, _ in keep]
+            self._labels = [l for _, l in keep]
+            for i, l in zip(ids, labs):
+                del self._by_id[i]
+                self._meta.pop(l, None)
+                self._docs.pop(l, None)
+            self._saved()
+
+    def peek(self, limit: int = 10) -> dict:
+        return self.get(limit=limit)
+
+
+class PersistentClient:
+    """Minimal stand-in for chromadb.PersistentClient(path) as the reference drives it (utils.py:113-130)."""
+
+    def __init__(self, path: str = "chroma_data", device: int = 0, dtype: str = "f32"):
+        self.path = path
+        self.device = device
+        self.dtype = dtype
+        os.makedirs(path, exist_ok=True)
+        self._open: Dict[str, FlatCollection] = {}
+
+    def list_collections(self) -> List[str]:
+        names = {n[: -len(".meta.json")] for n in os.listdir(self.path) if n.endswith(".meta.json")}
+        return sorted(names | set(self._open))
+
+    def get_collection(self, name: str) -> FlatCollection:
+        if name in self._open:
+            return self._open[name]
+        if name not in self.list_collections():
+            raise ValueError(f"Collection {name} does not exist.")
+        col = FlatCollection(name, persist_dir=self.path, device=self.device, dtype=self.dtype)
+        self._open[name] = col
+        return col
+
+    def create_collection(self, name: str, metadata: Optional[dict] = None) -> FlatCollection:
+        if name in self.list_collections():
+            raise ValueError(f"Collection {name} already exists.")
+        col = FlatCollection(name, metadata=metadata, persist_dir=self.path, device=self.device, dtype=self.dtype)
+        col.persist()
+        self._open[name] = col
+        return col
+
+    def get_or_create_collection(self, name: str, metadata: Optional[dict] = None) -> FlatCollection:
+        return self.get_collection(name) if name in self.list_collections() else self.create_collection(name, metadata)
+
+    def delete_collection(self, name: str) -> None:
+        self._open.pop(name, None)
+        for suffix in (".meta.json", ".index.mmiss"):
+            p = os.path.join(self.path, name + suffix)
+            if os.path.exists(p):
+                os.remove(p)

@@ -336,11 +336,11 @@ extern "C" int mmiss_encoder_destroy(mmiss_encoder* enc) {
     return MMISS_OK;
 }
 
-extern "C" int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream) {
+extern "C" int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream, int32_t use_own) {
     if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
     std::lock_guard<std::mutex> lk(enc->mu);
     enc->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
-    enc->has_user_stream = hip_stream != nullptr;
+    enc->has_user_stream = use_own == 0;
     return MMISS_OK;
 }
 

@@ -157,11 +157,11 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
     return MMISS_OK;
 }
 
-extern "C" int mmiss_index_set_stream(mmiss_index* ix, void* hip_stream) {
+extern "C" int mmiss_index_set_stream(mmiss_index* ix, void* hip_stream, int32_t use_own) {
     if (!ix) MM_FAIL(MMISS_ERR_ARG, "null index");
     std::lock_guard<std::mutex> lk(ix->mu);
     ix->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
-    ix->has_user_stream = hip_stream != nullptr;
+    ix->has_user_stream = use_own == 0;
     return MMISS_OK;
 }
 
@@ -552,7 +552,7 @@ extern "C" int mmiss_blend(int device, void* hip_stream, const float* img, const
         MM_HIP(hipGetLastError());
     }
     if (!out_dev) MM_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
-    if (!out_dev || bi.p || bt.p || !hip_stream) MM_HIP(hipStreamSynchronize(st));
+    if (!out_dev || bi.p || bt.p) MM_HIP(hipStreamSynchronize(st));
     return MMISS_OK;
 }
 
@@ -587,6 +587,6 @@ extern "C" int mmiss_merge_topk(int device, void* hip_stream, const float* dist,
         MM_HIP(hipMemcpyAsync(out_labels, dol, n_out * 8, hipMemcpyDeviceToHost, st));
         if (out_count) MM_HIP(hipMemcpyAsync(out_count, doc, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
     }
-    if (!out_dev || bd.p || bl.p || !hip_stream) MM_HIP(hipStreamSynchronize(st));
+    if (!out_dev || bd.p || bl.p) MM_HIP(hipStreamSynchronize(st));
     return MMISS_OK;
 }

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     }
     const double nrm = sqrt(wave_butterfly_sum(acc));
     for (int d = lane; d < D; d += 64) {
-        const float y = (float)((double)x[d] / nrm);
+        float y = (float)((double)x[d] / nrm);
+        asm volatile("" : "+v"(y));  // keep the float rounding: storage = RNE_f16(RNE_f32(x / nrm)), two roundings
         dst[r * D + d] = (T)y;
     }
 }
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
     }
     const double nrm = sqrt(wave_butterfly_sum(acc));
     for (int d = lane; d < D; d += 64) {
-        const float y = (float)((double)x[d] / nrm);
+        float y = (float)((double)x[d] / nrm);
+        asm volatile("" : "+v"(y));
         qn[(size_t)r * D + d] = y;
         qs[(size_t)r * D + d] = (T)y;
     }
@@ -486,6 +488,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ img, const float* __restrict__ txt,
                                                     float w_img, float w_txt, int Q, int D, float* __restrict__ out) {
+#pragma clang fp contract(off)
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= Q) return;
@@ -500,14 +503,22 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ im
     const double ni = sqrt(wave_butterfly_sum(ai)), nt = sqrt(wave_butterfly_sum(at));
     double ac = 0.0;
     for (int d = lane; d < D; d += 64) {
-        const float yi = (float)((double)xi[d] / ni), yt = (float)((double)xt[d] / nt);
-        const float c = __fadd_rn(__fmul_rn(w_img, yi), __fmul_rn(w_txt, yt));
+        float yi = (float)((double)xi[d] / ni), yt = (float)((double)xt[d] / nt);
+        asm volatile("" : "+v"(yi), "+v"(yt));
+        float pi = w_img * yi, pt = w_txt * yt;
+        asm volatile("" : "+v"(pi), "+v"(pt));  // two rounded products, then one rounded add
+        float c = pi + pt;
+        asm volatile("" : "+v"(c));
         ac = ac + (double)c * (double)c;
     }
     const double nc = sqrt(wave_butterfly_sum(ac));
     for (int d = lane; d < D; d += 64) {
-        const float yi = (float)((double)xi[d] / ni), yt = (float)((double)xt[d] / nt);
-        const float c = __fadd_rn(__fmul_rn(w_img, yi), __fmul_rn(w_txt, yt));
+        float yi = (float)((double)xi[d] / ni), yt = (float)((double)xt[d] / nt);
+        asm volatile("" : "+v"(yi), "+v"(yt));
+        float pi = w_img * yi, pt = w_txt * yt;
+        asm volatile("" : "+v"(pi), "+v"(pt));
+        float c = pi + pt;
+        asm volatile("" : "+v"(c));
         out[(size_t)r * D + d] = (float)((double)c / nc);
     }
 }

@@ -70,6 +70,54 @@ def _is_torch(x) -> bool:
     return hasattr(x, "data_ptr")
 
 
+def random_state_dict(shape: ClipShape, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded random-init weights in the HF state_dict layout (no checkpoints exist offline): matrix stds
+    follow HF's init table (HF:modeling_clip.py:404-437); biases / LayerNorm affine get small random values so
+    every term of the forward is exercised. Used by bench.py, smoke() and the parity tests."""
+    s = ClipShape.from_any(shape)
+    rng = np.random.Generator(np.random.Philox(seed))
+    w: Dict[str, np.ndarray] = {}
+
+    def normal(name, shp, std):
+        w[name] = (rng.standard_normal(shp, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    def ln(prefix, d):
+        w[prefix + ".weight"] = (1.0 + 0.1 * rng.standard_normal(d, dtype=np.float32)).astype(np.float32)
+        w[prefix + ".bias"] = (0.1 * rng.standard_normal(d, dtype=np.float32)).astype(np.float32)
+
+    def tower(prefix, d, layers, mlp):
+        in_std = d ** -0.5 * (2 * layers) ** -0.5
+        out_std = d ** -0.5
+        fc_std = (2 * d) ** -0.5
+        for i in range(layers):
+            p = f"{prefix}.encoder.layers.{i}."
+            for nm in ("q_proj", "k_proj", "v_proj"):
+                normal(p + f"self_attn.{nm}.weight", (d, d), in_std)
+                normal(p + f"self_attn.{nm}.bias", (d,), 0.02)
+            normal(p + "self_attn.out_proj.weight", (d, d), out_std)
+            normal(p + "self_attn.out_proj.bias", (d,), 0.02)
+            ln(p + "layer_norm1", d)
+            ln(p + "layer_norm2", d)
+            normal(p + "mlp.fc1.weight", (mlp, d), fc_std)
+            normal(p + "mlp.fc1.bias", (mlp,), 0.02)
+            normal(p + "mlp.fc2.weight", (d, mlp), in_std)
+            normal(p + "mlp.fc2.bias", (d,), 0.02)
+
+    normal("vision_model.embeddings.class_embedding", (s.v_hidden,), s.v_hidden ** -0.5)
+    normal("vision_model.embeddings.patch_embedding.weight", (s.v_hidden, 3, s.v_patch, s.v_patch), 0.02)
+    normal("vision_model.embeddings.position_embedding.weight", (s.v_tokens, s.v_hidden), 0.02)
+    ln("vision_model.pre_layrnorm", s.v_hidden)
+    tower("vision_model", s.v_hidden, s.v_layers, s.v_mlp)
+    ln("vision_model.post_layernorm", s.v_hidden)
+    normal("visual_projection.weight", (s.proj_dim, s.v_hidden), s.v_hidden ** -0.5)
+    normal("text_model.embeddings.token_embedding.weight", (s.t_vocab, s.t_hidden), 0.02)
+    normal("text_model.embeddings.position_embedding.weight", (s.t_ctx, s.t_hidden), 0.02)
+    tower("text_model", s.t_hidden, s.t_layers, s.t_mlp)
+    ln("text_model.final_layer_norm", s.t_hidden)
+    normal("text_projection.weight", (s.proj_dim, s.t_hidden), s.t_hidden ** -0.5)
+    return w
+
+
 class ClipEncoder:
     """One encoder handle = both towers' weights in HBM + workspaces, on one GPU, one HIP stream."""
 
@@ -124,9 +172,9 @@ class ClipEncoder:
 
     def _sync_stream(self, x):
         if _is_torch(x) and x.is_cuda:
-            _lib.check(self._lib.mmiss_encoder_set_stream(self._h, _lib.current_stream_ptr(x.device)))
+            _lib.check(self._lib.mmiss_encoder_set_stream(self._h, _lib.current_stream_ptr(x.device), 0))
         else:
-            _lib.check(self._lib.mmiss_encoder_set_stream(self._h, None))
+            _lib.check(self._lib.mmiss_encoder_set_stream(self._h, None, 1))
 
     def encode_image(self, pixels, out=None):
         """pixels: float32 [B,3,S,S] CLIP-normalised (numpy, or torch tensor on this GPU) -> float32 [B,proj] unit rows

@@ -47,9 +47,9 @@ class FlatIndex:
 
     def _sync_stream(self, x):
         if _is_torch(x) and x.is_cuda:
-            _lib.check(self._lib.mmiss_index_set_stream(self._h, _lib.current_stream_ptr(x.device)))
+            _lib.check(self._lib.mmiss_index_set_stream(self._h, _lib.current_stream_ptr(x.device), 0))
         else:
-            _lib.check(self._lib.mmiss_index_set_stream(self._h, None))
+            _lib.check(self._lib.mmiss_index_set_stream(self._h, None, 1))
 
     # ------------------------------------------------------------------ mutation
     def add(self, vecs, labels) -> None:
