@@ -136,7 +136,7 @@ int build_tower(mmiss_encoder* e, Tower& tw, const std::string& prefix, int hidd
 
 int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     if (tw.ws_batch >= max_batch) return MMISS_OK;
-    const int64_t Mp = round_up((int64_t)max_batch * tw.T, 128);
+    const int64_t Mp = round_up((int64_t)max_batch * tw.T, 128) + 192;  // room for any tile height (128/160/192)
     const int64_t Bp = round_up(max_batch, 128);
     const int d = tw.hidden;
     MM_TRY(alloc_zero(tw.x, (size_t)Mp * d * 4));
@@ -159,8 +159,10 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
 // the transformer stack shared by both towers; x holds the embeddings on entry
 int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) {
     const int d = tw.hidden, M = B * tw.T;
-    const int Mp = (int)round_up(M, 128);
     const float eps = e->cfg.ln_eps;
+    // per-GEMM tile height (fills the 256 CUs x 2 blocks evenly) and the row count padded to it
+    const int bm_qkv = gemm_pick_bm(M, 3 * d), bm_d = gemm_pick_bm(M, d), bm_mlp = gemm_pick_bm(M, tw.mlp);
+    auto padded = [&](int bm) { return (int)round_up(M, bm); };
     auto tap = [&](int which) -> int {
         if (e->record_taps && tw.taps.p)
             MM_HIP(hipMemcpyAsync(tw.taps.as<float>() + (size_t)which * tw.tap_stride, tw.x.p, (size_t)M * d * 4,
@@ -174,19 +176,19 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
                                 d, eps));
         GemmEpi ep{};
         ep.out = tw.qkv.p; ep.bias = L.bqkv.as<float>(); ep.ldo = 3 * d; ep.m_valid = M;
-        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, 0, tw.h.p, L.wqkv.p, ep, Mp, 3 * d, d));
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
         MM_TRY(launch_attention(st, tw.qkv.p, tw.ctx.p, B, tw.T, tw.heads, causal));
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = M;
-        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, 0, tw.ctx.p, L.wo.p, ep, Mp, d, d));
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
                                 d, eps));
         ep = GemmEpi{};
         ep.out = tw.u.p; ep.bias = L.b1.as<float>(); ep.ldo = tw.mlp; ep.m_valid = M;
-        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, 0, tw.h.p, L.w1.p, ep, Mp, tw.mlp, d));
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.h.p, L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = M;
-        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, 0, tw.u.p, L.w2.p, ep, Mp, d, tw.mlp));
+        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         MM_TRY(tap(l + 1));
     }
     return MMISS_OK;
@@ -214,13 +216,14 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
     Tower& tw = e->vis;
     const int d = tw.hidden, S = e->cfg.v_image, P = e->cfg.v_patch;
     const int Mpatch = B * e->G * e->G;
-    const int Mpp = (int)round_up(Mpatch, 128);
+    const int bm_p = gemm_pick_bm(Mpatch, d);
+    const int Mpp = (int)round_up(Mpatch, bm_p);
     MM_TRY(launch_im2col(st, pix_dev, src_u8, e->patches.p, B, S, P, e->Kp));
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, st, tw.x.as<float>(),
                        e->cls.as<float>(), tw.pos.as<float>(), B, tw.T, d);
     GemmEpi ep{};
     ep.out = tw.x.p; ep.aux = tw.pos.as<float>(); ep.ldo = d; ep.m_valid = Mpatch; ep.p0 = e->G * e->G; ep.p1 = tw.T;
-    MM_TRY(launch_gemm(st, MMISS_EPI_PATCH_F32, 0, e->patches.p, e->patch_w.p, ep, Mpp, d, e->Kp));
+    MM_TRY(launch_gemm(st, MMISS_EPI_PATCH_F32, bm_p, e->patches.p, e->patch_w.p, ep, Mpp, d, e->Kp));
     // pre_layrnorm, in place on the fp32 residual stream (HF:modeling_clip.py:640)
     MM_TRY(launch_layernorm(st, tw.x.as<float>(), e->pre_g.as<float>(), e->pre_b.as<float>(), tw.x.p, false, nullptr,
                             B * tw.T, d, e->cfg.ln_eps));
@@ -410,7 +413,7 @@ static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8
     const int maxb = enc->cfg.max_batch_image, S = enc->cfg.v_image, P = enc->cfg.proj_dim;
     MM_TRY(ensure_tower_ws(enc, enc->vis, maxb, P));
     if (!enc->patches.p) {
-        const int64_t Mpp = round_up((int64_t)maxb * enc->G * enc->G, 128);
+        const int64_t Mpp = round_up((int64_t)maxb * enc->G * enc->G, 128) + 192;
         MM_TRY(alloc_zero(enc->patches, (size_t)Mpp * enc->Kp * 2));
     }
     const bool in_dev = mmiss_is_device_ptr(pixels), out_dev = mmiss_is_device_ptr(out);

@@ -13,7 +13,7 @@ struct mmiss_index {
     DevBuf rows, labels_d;
     std::vector<int64_t> labels_h;
     // scratch
-    DevBuf stage, qn, qs, qstage, lists_s, lists_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, tmp_rows, tmp_labels;
+    DevBuf stage, qn, qs, qstage, lists_s, lists_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, gmax;
     hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
 };
 
@@ -370,7 +370,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     if (ncand > 2048) MM_FAIL(MMISS_ERR_UNSUPPORTED, "mmiss_index_query: k = %d too large (max 2040)", k);
 
     // queries -> device, canonical normalisation
-    const int Qpad = (int)round_up(Q, 64);
+    const int Qpad = (int)round_up(Q, 128);
     const float* qsrc = queries;
     if (!mmiss_is_device_ptr(queries)) {
         MM_TRY(ix->qstage.ensure((size_t)Q * D * 4));
@@ -391,9 +391,45 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         MM_HIP(hipGetLastError());
     }
 
+    // batched path: f16 rows, more than one MFMA tile of queries, single page
+    const bool dense = (N > 0) && ix->dtype == MMISS_F16 && Q > 16 && pages == 1;
     MM_TRY(ix->cand.ensure((size_t)Q * ncand * 4));
     if (N == 0) {
         MM_HIP(hipMemsetAsync(ix->cand.p, 0xff, (size_t)Q * ncand * 4, st));  // all -1
+    } else if (dense) {
+        const int64_t Npad = round_up(N, 128);  // capacity is a multiple of 128: the pad rows are readable, and masked
+        const int ng = (int)(Npad / 16);
+        MM_TRY(ix->gmax.ensure((size_t)Qpad * ng * 4));
+        GemmEpi ep{};
+        ep.out = ix->gmax.p; ep.ldo = ng; ep.m_valid = Q; ep.p0 = (int)N; ep.m_fast = 1;
+        {
+            MM_PROF("score_gemm_f16", st, 2.0 * Q * (double)N * D, (double)N * D * 2);
+            MM_TRY((launch_gemm_inst<_Float16, 128, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Qpad, (int)Npad, D)));
+        }
+        const int units = (ng + 255) / 256;
+        int splits = (1024 + Q - 1) / Q;
+        if (splits > units) splits = units;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+        MM_TRY(ix->lists_s.ensure((size_t)splits * Q * kp * 4));
+        MM_TRY(ix->lists_r.ensure((size_t)splits * Q * kp * 4));
+        SelectArgs sa{};
+        sa.G = ix->gmax.as<float>(); sa.ldg = ng; sa.ng = ng; sa.kp = kp; sa.Q = Q;
+        sa.out_s = ix->lists_s.as<float>(); sa.out_r = ix->lists_r.as<int32_t>();
+        {
+            MM_PROF("select_topk", st, 0.0, (double)Q * ng * 4);
+            hipLaunchKernelGGL(select_topk_kernel, dim3(Q, splits), dim3(256), 0, st, sa);
+            MM_HIP(hipGetLastError());
+        }
+        MergeArgs m{};
+        m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
+        m.L = splits; m.Q = Q; m.kp = kp;
+        m.cand = ix->cand.as<int32_t>(); m.cand_stride = ncand; m.page_off = 0;
+        {
+            MM_PROF("merge_lists", st, 0.0, (double)splits * Q * kp * 8);
+            hipLaunchKernelGGL(merge_lists_kernel, dim3(Q), dim3(256), 0, st, m);
+            MM_HIP(hipGetLastError());
+        }
     } else {
         const ScanPlan p = plan_scan(D, ix->elt, Q, kp, N);
         MM_TRY(ix->lists_s.ensure((size_t)p.slabs * Q * kp * 4));
@@ -432,12 +468,13 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     {
         RerankArgs r{};
         r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand.as<int32_t>();
-        r.cand_stride = ncand; r.ncand = ncand; r.labels = ix->labels_d.as<int64_t>(); r.k = k;
+        r.cand_stride = ncand; r.ncand = dense ? ncand * 16 : ncand; r.group_mode = dense ? 1 : 0; r.nrows = N;
+        r.labels = ix->labels_d.as<int64_t>(); r.k = k;
         r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
         int npow = 1;
-        while (npow < ncand) npow <<= 1;
+        while (npow < r.ncand) npow <<= 1;
         const int lds = npow * 12 + 16;
-        MM_PROF("rerank", st, 2.0 * Q * ncand * D, (double)Q * ncand * D * ix->elt);
+        MM_PROF("rerank", st, 2.0 * Q * r.ncand * D, (double)Q * r.ncand * D * ix->elt);
         if (ix->dtype == MMISS_F16)
             hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(Q), dim3(256), lds, st, r);
         else

@@ -1,19 +1,21 @@
-// gemm_bf16.h — bf16 MFMA GEMM for the CLIP towers:  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue).
+// gemm_bf16.h — 16-bit MFMA GEMM:  C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue), bf16 or f16 inputs.
 //
-// Covers K1 (patch projection), K3 (QKV), K5 (out-proj + residual), K6 (FC1 + QuickGELU),
-// K7 (FC2 + residual) and K8's projection of SURVEY.md §2.2. The arithmetic it replaces is
-// nn.Linear / nn.Conv2d inside HF:modeling_clip.py:148-154,293-296,338-350,674-675.
+// bf16: K1 (patch projection), K3 (QKV), K5 (out-proj + residual), K6 (FC1 + QuickGELU), K7 (FC2 + residual)
+//       and K8's projection of SURVEY.md §2.2 — the nn.Linear / nn.Conv2d arithmetic of
+//       HF:modeling_clip.py:148-154,293-296,338-350,674-675.
+// f16 : K11's batched score pass (queries x corpus rows) with the GROUPMAX epilogue (retrieval_kernels.h).
 //
-// Both operands are K-contiguous (nn.Linear stores [out,in]), which is exactly the per-lane fragment
-// shape of v_mfma_f32_16x16x32_bf16 (8 consecutive k per lane), so neither needs a transpose.
-// The MFMA "A" operand is the WEIGHT tile and the "B" operand the ACTIVATION tile: the accumulator
-// then holds 4 consecutive n (output features) per lane for one m (token), so epilogue stores are
-// 8-byte (bf16) / 16-byte (f32) vectors along the contiguous output dimension.
+// Both operands are K-contiguous (nn.Linear stores [out,in]; index rows are [row, dim]), which is exactly the
+// per-lane fragment shape of v_mfma_f32_16x16x32_{bf16,f16} (8 consecutive k per lane): no transposes.
+// The MFMA "A" operand is the W tile and the "B" operand the A (activation / query) tile: the accumulator
+// then holds 4 consecutive n per lane for one m, so epilogue stores are 8-byte (bf16) / 16-byte (f32)
+// vectors along the contiguous output dimension.
 //
-// v1 structure (guide §5 "minimum 2-phase"): 128x128x64 tile, 4 waves (2x2, 64x64 per wave),
-// global_load_lds dwordx4 staging into a double-buffered, XOR-swizzled LDS image (swizzle applied to
-// the SOURCE address and to the read, destination linear — guide §5.4 rule 21), one barrier per K-tile,
-// 2 workgroups per CU so one block's staging wait overlaps the other's MFMAs.
+// Structure (guide §5 "minimum 2-phase"): BM x 128 x 64 tile (BM = 128/160/192, chosen per shape so the grid
+// fills the 256 CUs x 2 resident blocks evenly), 4 waves (2x2), global_load_lds dwordx4 staging into a
+// double-buffered, XOR-swizzled LDS image (swizzle on the SOURCE address and on the read, destination
+// linear — guide §5.4 rule 21), one barrier per K-tile, 2 workgroups per CU so one block's staging wait
+// overlaps the other's MFMAs.
 #pragma once
 #include "common.h"
 
@@ -23,13 +25,14 @@ struct GemmEpi {
     const float* aux;   // PATCH: position table [T, N]
     int ldo;            // output row stride (elements)
     int m_valid;        // rows >= m_valid are not stored
-    int p0, p1;         // PATCH: p0 = patches per image (G), p1 = tokens per image (T)
+    int p0, p1;         // PATCH: p0 = patches per image (G), p1 = tokens per image (T). GROUPMAX: p0 = valid n
+    int m_fast;         // block order: 0 = n fastest (blocks sharing an A panel adjacent), 1 = m fastest
 };
 
-#define GEMM_BM 128
+#define MMISS_EPI_GROUPMAX_F32 5  // internal: out f32 [M, N/16] = max over the lane's 16 n (see decode below)
+
 #define GEMM_BN 128
 #define GEMM_BK 64
-#define GEMM_LDS_BYTES (2 * (GEMM_BM + GEMM_BN) * GEMM_BK * 2)
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -42,84 +45,81 @@ __device__ __forceinline__ float quick_gelu(float x) {
 }
 
 // XCD-aware, bijective block remap (guide §5 "XCD swizzle must be bijective"): blocks that share an
-// XCD (equal bid % 8) get a contiguous run of tiles, so an activation row-panel is fetched into one L2.
+// XCD (equal bid % 8) get a contiguous run of tiles, so a shared operand panel is fetched into one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + (bid >> 3);
 }
 
-template <int EPI>
-__device__ __forceinline__ void gemm_store4(const GemmEpi& ep, int m, int n, f32x4 v) {
-    if (m >= ep.m_valid) return;
-    if constexpr (EPI == MMISS_EPI_F32) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n) = v;
-    } else if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + n);
-        float y[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            y[i] = v[i] + b[i];
-            if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[i] = quick_gelu(y[i]);
-        }
-        u32x2 pk;
-        pk[0] = pack_bf16x2(y[0], y[1]);
-        pk[1] = pack_bf16x2(y[2], y[3]);
-        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n) = pk;
-    } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + n);
-        float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
-        f32x4 x = *reinterpret_cast<const f32x4*>(p);
-        x += v + b;
-        *reinterpret_cast<f32x4*>(p) = x;
-    } else if constexpr (EPI == MMISS_EPI_PATCH_F32) {
-        const int img = m / ep.p0, patch = m - img * ep.p0;
-        const f32x4 pos = *reinterpret_cast<const f32x4*>(ep.aux + (size_t)(1 + patch) * ep.ldo + n);
-        float* p = reinterpret_cast<float*>(ep.out) + ((size_t)img * ep.p1 + 1 + patch) * ep.ldo + n;
-        *reinterpret_cast<f32x4*>(p) = v + pos;
-    }
+// GROUPMAX group g <-> rows: g = ((bn*2 + wn)*4 + fg); member e (0..15) is row
+//   bn*128 + wn*64 + 4*fg + (e >> 2)*16 + (e & 3)
+__host__ __device__ __forceinline__ int64_t groupmax_row(int64_t g, int e) {
+    const int64_t fg = g & 3, wn = (g >> 2) & 1, bn = g >> 3;
+    return bn * 128 + wn * 64 + 4 * fg + (e >> 2) * 16 + (e & 3);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_128x128(const bf16_t* __restrict__ A,
-                                                            const bf16_t* __restrict__ W, int M, int N,
-                                                            int K, GemmEpi ep) {
+template <typename IN> struct MfmaIn;
+template <> struct MfmaIn<__bf16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct MfmaIn<_Float16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename IN, int BM, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M,
+                                                        int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename MfmaIn<IN>::frag frag;
+    constexpr int JT = BM / 32;               // 16-row m sub-tiles per wave (wave tile = BM/2 x 64)
+    constexpr int A_BYTES = BM * 128, W_BYTES = GEMM_BN * 128, BUF = A_BYTES + W_BYTES;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nbn = N / GEMM_BN;
-    const int nwg = (M / GEMM_BM) * nbn;
+    const int nbm = M / BM, nbn = N / GEMM_BN;
+    const int nwg = nbm * nbn;
     const int wg = xcd_remap(blockIdx.x, nwg);
-    const int bm = wg / nbn, bn = wg - bm * nbn;
+    int bm, bn;
+    if (ep.m_fast) { bn = wg / nbm; bm = wg - bn * nbm; }
+    else           { bm = wg / nbn; bn = wg - bm * nbn; }
 
-    const bf16_t* Ab = A + (size_t)bm * GEMM_BM * K;
-    const bf16_t* Wb = W + (size_t)bn * GEMM_BN * K;
+    const IN* Ab = A + (size_t)bm * BM * K;
+    const IN* Wb = W + (size_t)bn * GEMM_BN * K;
 
-    // staging: one wave-instruction = 8 rows x 128 B; lane -> (row r_in, 16-B slot p); slot p of
-    // row r holds global chunk p ^ (r & 7)
+    // staging: one wave-instruction = 8 rows x 128 B; lane -> (row r_in, 16-B slot p); slot p of row r
+    // holds global chunk p ^ (r & 7)
     const int r_in = lane >> 3, p = lane & 7;
     const int src_chunk = (p ^ r_in) * 8;  // elements
     auto stage = [&](int buf, int kt) {
-        char* sA = smem + buf * 32768;
-        char* sW = sA + 16384;
+        char* sA = smem + buf * BUF;
+        char* sW = sA + A_BYTES;
         const size_t koff = (size_t)kt * GEMM_BK + src_chunk;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const int rowblk = wave * (BM / 32) + i;
+            glds16(Ab + (size_t)(rowblk * 8 + r_in) * K + koff, sA + rowblk * 1024);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rowblk = wave * 4 + i;
-            const int row = rowblk * 8 + r_in;
-            glds16(Ab + (size_t)row * K + koff, sA + rowblk * 1024);
-            glds16(Wb + (size_t)row * K + koff, sW + rowblk * 1024);
+            glds16(Wb + (size_t)(rowblk * 8 + r_in) * K + koff, sW + rowblk * 1024);
         }
     };
 
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
-    f32x4 acc[4][4];
+    f32x4 acc[4][JT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = K / GEMM_BK;
     stage(0, 0);
@@ -129,78 +129,162 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128(const bf16_t* __rest
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) stage(cur ^ 1, t + 1);
-        const char* sA = smem + cur * 32768;
-        const char* sW = sA + 16384;
+        const char* sA = smem + cur * BUF;
+        const char* sW = sA + A_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 wf[4], af[4];
+            frag wf[4], af[JT];
             const int chunk = 4 * s + fg;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wn * 64 + i * 16 + fr;
-                wf[i] = *reinterpret_cast<const bf16x8*>(sW + row * 128 + ((chunk ^ (row & 7)) << 4));
+                wf[i] = *reinterpret_cast<const frag*>(sW + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wm * 64 + j * 16 + fr;
-                af[j] = *reinterpret_cast<const bf16x8*>(sA + row * 128 + ((chunk ^ (row & 7)) << 4));
+            for (int j = 0; j < JT; ++j) {
+                const int row = wm * (BM / 2) + j * 16 + fr;
+                af[j] = *reinterpret_cast<const frag*>(sA + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < JT; ++j) acc[i][j] = MfmaIn<IN>::mma(wf[i], af[j], acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // acc[i][j][reg] = C[m = .. + j*16 + fr][n = .. + i*16 + 4*fg + reg]
-    const int m_base = bm * GEMM_BM + wm * 64 + fr;
+    // acc[i][j][reg] = C[m = m_base + j*16][n = n_base + i*16 + reg]
+    const int m_base = bm * BM + wm * (BM / 2) + fr;
     const int n_base = bn * GEMM_BN + wn * 64 + 4 * fg;
+
+    if constexpr (EPI == MMISS_EPI_GROUPMAX_F32) {
+        const int g = (bn * 2 + wn) * 4 + fg;
+        float* out = reinterpret_cast<float*>(ep.out);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < JT; ++j) {
+            float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gemm_store4<EPI>(ep, m_base + j * 16, n_base + i * 16, acc[i][j]);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (n_base + i * 16 + r < ep.p0) ? acc[i][j][r] : -INFINITY;
+                    mx = fmaxf(mx, v);
+                }
+            const int m = m_base + j * 16;
+            if (m < ep.m_valid) out[(size_t)m * ep.ldo + g] = mx;
+        }
+        return;
+    }
+
+    f32x4 bias[4];
+    if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + n_base + i * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int m = m_base + j * 16;
+        if (m >= ep.m_valid) continue;
+        if constexpr (EPI == MMISS_EPI_F32) {
+            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = acc[i][j];
+        } else if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16) {
+            uint16_t* row = reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_base;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = acc[i][j][r] + bias[i][r];
+                    if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[r] = quick_gelu(y[r]);
+                }
+                u32x2 pk;
+                pk[0] = pack_bf16x2(y[0], y[1]);
+                pk[1] = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<u32x2*>(row + i * 16) = pk;
+            }
+        } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
+            f32x4 x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + i * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = x[i] + acc[i][j] + bias[i];
+        } else if constexpr (EPI == MMISS_EPI_PATCH_F32) {
+            const int img = m / ep.p0, patch = m - img * ep.p0;
+            const float* pos = ep.aux + (size_t)(1 + patch) * ep.ldo + n_base;
+            float* row = reinterpret_cast<float*>(ep.out) + ((size_t)img * ep.p1 + 1 + patch) * ep.ldo + n_base;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f32x4*>(row + i * 16) = acc[i][j] + *reinterpret_cast<const f32x4*>(pos + i * 16);
+        }
+    }
 }
 
-// algorithmic flops / bytes of one launch (for mmiss_prof_*)
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 
-static int launch_gemm(hipStream_t st, int epi, int variant, const void* A, const void* W, const GemmEpi& ep,
-                       int M, int N, int K) {
-    (void)variant;
-    if (M <= 0 || N <= 0 || K <= 0 || (M % GEMM_BM) || (N % GEMM_BN) || (K % GEMM_BK))
-        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, GEMM_BM,
-                GEMM_BN, GEMM_BK);
-    const int nwg = (M / GEMM_BM) * (N / GEMM_BN);
-    const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
-    const bf16_t* w = reinterpret_cast<const bf16_t*>(W);
+// tile height for a GEMM over M_pad rows (M_pad must be a multiple of the returned BM): the candidate that
+// wastes the fewest block slots of the 256 CU x 2 resident-block machine
+static inline int gemm_pick_bm(int64_t M_rows, int N) {
+    int best = 128;
+    double best_cost = 1e300;
+    for (int bm : {128, 160, 192}) {
+        const int64_t tiles = ((M_rows + bm - 1) / bm) * (N / GEMM_BN);
+        const int64_t rounds = (tiles + 511) / 512;
+        const double cost = (double)rounds * bm * (1.0 + 0.03 * (bm != 128));  // time ~ rounds x tile height
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = bm; }
+    }
+    return best;
+}
+
+template <typename IN, int BM, int EPI>
+static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+    constexpr int LDS = 2 * (BM + GEMM_BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const int nwg = (M / BM) * (N / GEMM_BN);
+    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI>), dim3(nwg), dim3(256), LDS, st, reinterpret_cast<const IN*>(A),
+                       reinterpret_cast<const IN*>(W), M, N, K, ep);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+template <typename IN, int EPI>
+static int launch_gemm_bm(hipStream_t st, int bm, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+    switch (bm) {
+        case 128: return launch_gemm_inst<IN, 128, EPI>(st, A, W, ep, M, N, K);
+        case 160: return launch_gemm_inst<IN, 160, EPI>(st, A, W, ep, M, N, K);
+        case 192: return launch_gemm_inst<IN, 192, EPI>(st, A, W, ep, M, N, K);
+    }
+    MM_FAIL(MMISS_ERR_ARG, "gemm: unsupported tile height %d", bm);
+}
+
+// bf16 GEMM of the CLIP towers. `bm` = tile height (128/160/192; 0 = 128); M must be a multiple of it.
+static int launch_gemm(hipStream_t st, int epi, int bm, const void* A, const void* W, const GemmEpi& ep, int M, int N,
+                       int K) {
+    if (bm == 0) bm = 128;
+    if (M <= 0 || N <= 0 || K <= 0 || (M % bm) || (N % GEMM_BN) || (K % GEMM_BK))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, bm, GEMM_BN,
+                GEMM_BK);
     static const char* names[] = {"gemm_bf16_f32", "gemm_bf16_bias", "gemm_bf16_bias_qgelu",
                                   "gemm_bf16_bias_resid", "gemm_bf16_patch"};
     if (epi < 0 || epi > 4) MM_FAIL(MMISS_ERR_ARG, "gemm: bad epilogue %d", epi);
     const int out_elt = (epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16) ? 2 : 4;
-    const double bytes = 2.0 * ((double)M * K + (double)N * K) + (double)out_elt * M * N *
-                                                                      (epi == MMISS_EPI_BIAS_RESID_F32 ? 2 : 1);
-    MM_PROF(names[epi], st, gemm_flops(ep.m_valid < M ? ep.m_valid : M, N, K), bytes);
-#define GEMM_LAUNCH(E)                                                                                    \
-    case E: {                                                                                             \
-        static bool attr_done = false;                                                                    \
-        if (!attr_done) {                                                                                 \
-            MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_128x128<E>),              \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));      \
-            attr_done = true;                                                                             \
-        }                                                                                                 \
-        hipLaunchKernelGGL(gemm_bf16_128x128<E>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, a, w, M, N, K, ep); \
-    } break;
+    const int mv = ep.m_valid < M ? ep.m_valid : M;
+    const double bytes = 2.0 * ((double)mv * K + (double)N * K) +
+                         (double)out_elt * mv * N * (epi == MMISS_EPI_BIAS_RESID_F32 ? 2 : 1);
+    MM_PROF(names[epi], st, gemm_flops(mv, N, K), bytes);
     switch (epi) {
-        GEMM_LAUNCH(MMISS_EPI_F32)
-        GEMM_LAUNCH(MMISS_EPI_BIAS_BF16)
-        GEMM_LAUNCH(MMISS_EPI_BIAS_QGELU_BF16)
-        GEMM_LAUNCH(MMISS_EPI_BIAS_RESID_F32)
-        GEMM_LAUNCH(MMISS_EPI_PATCH_F32)
+        case MMISS_EPI_F32: return launch_gemm_bm<__bf16, MMISS_EPI_F32>(st, bm, A, W, ep, M, N, K);
+        case MMISS_EPI_BIAS_BF16: return launch_gemm_bm<__bf16, MMISS_EPI_BIAS_BF16>(st, bm, A, W, ep, M, N, K);
+        case MMISS_EPI_BIAS_QGELU_BF16: return launch_gemm_bm<__bf16, MMISS_EPI_BIAS_QGELU_BF16>(st, bm, A, W, ep, M, N, K);
+        case MMISS_EPI_BIAS_RESID_F32: return launch_gemm_bm<__bf16, MMISS_EPI_BIAS_RESID_F32>(st, bm, A, W, ep, M, N, K);
+        default: return launch_gemm_bm<__bf16, MMISS_EPI_PATCH_F32>(st, bm, A, W, ep, M, N, K);
     }
-#undef GEMM_LAUNCH
-    MM_HIP(hipGetLastError());
-    return MMISS_OK;
 }

@@ -13,6 +13,7 @@
 //     distances are bit-identical between the two, on any shard layout.
 #pragma once
 #include "common.h"
+#include "gemm_bf16.h"
 #include <math.h>
 #include <type_traits>
 
@@ -319,6 +320,86 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K11 stage 1 (batched path, Q > 16, f16 rows): the score pass is the f16 MFMA GEMM of gemm_bf16.h with the
+// GROUPMAX epilogue — G[q][g] = max of the approximate scores of the 16 rows of group g — so only 1/16 of the
+// Q x N score matrix ever leaves the registers. Every row of the true top-k' lies in one of the top-k' groups
+// by group max (a group's max bounds its members from above), so selecting k' GROUPS and re-scoring their
+// 16 x k' rows canonically in stage 2 loses nothing.
+//
+// select_topk_kernel: grid (Q, splits), 4 waves; each wave streams a contiguous run of G[q][:] and keeps its
+// best 64 entries SORTED ACROSS ITS LANES (no LDS): a value beating the wave's k'-th best is inserted by
+// ballot + popcount (its rank) + one shfl_up. After the first 64 values inserts are rare (~k' ln(n/k') per wave).
+// ------------------------------------------------------------------------------------------------
+struct SelectArgs {
+    const float* G;       // [Qpad, ldg]
+    int ldg;
+    int ng;               // valid groups per query
+    int kp;
+    float* out_s;         // [gridDim.y][Q][kp]
+    int32_t* out_r;       // group ids, -1 = none
+    int Q;
+};
+
+__device__ __forceinline__ void lane_list_insert(float& ls, int& lr, float xs, int xr, int lane) {
+    const unsigned long long better = __ballot(ls > xs || (ls == xs && lr < xr));
+    const int p = __popcll(better);  // the list is sorted best-first, so the better entries are lanes [0, p)
+    const float us = __shfl_up(ls, 1);
+    const int ur = __shfl_up(lr, 1);
+    if (lane > p) { ls = us; lr = ur; }
+    else if (lane == p) { ls = xs; lr = xr; }
+}
+
+__global__ __launch_bounds__(256) void select_topk_kernel(SelectArgs a) {
+    __shared__ float ms[4][32];
+    __shared__ int mr[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    const int nsplit = gridDim.y;
+    // this block's column range, in units of 256 columns
+    const int units = (a.ng + 255) / 256;
+    const int upb = (units + nsplit - 1) / nsplit;
+    const int c_begin = blockIdx.y * upb * 256;
+    int c_end = c_begin + upb * 256;
+    if (c_end > a.ng) c_end = a.ng;
+    const float* row = a.G + (size_t)q * a.ldg;
+
+    float ls = SCAN_NEG_INF;
+    int lr = SCAN_ROW_NONE;
+    float tau = SCAN_NEG_INF;
+    // wave w takes columns c_begin + 64*w + lane, stepping 256
+    for (int c0 = c_begin + wave * 64; c0 < c_end; c0 += 256) {
+        const int c = c0 + lane;
+        float s = SCAN_NEG_INF;
+        if (c < c_end) s = row[c];
+        unsigned long long m = __ballot(s > tau);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float xs = __shfl(s, src);
+            if (!(xs > tau)) continue;
+            lane_list_insert(ls, lr, xs, c0 + src, lane);
+            tau = __shfl(ls, a.kp - 1);
+        }
+    }
+    if (lane < 32) { ms[wave][lane] = ls; mr[wave][lane] = lr; }
+    __syncthreads();
+    if (wave == 0) {
+        float s = (lane < 32) ? ms[0][lane] : ms[1][lane - 32];
+        int r = (lane < 32) ? mr[0][lane] : mr[1][lane - 32];
+        wave_sort64(s, r, lane);
+        for (int w = 2; w < 4; ++w) {
+            if (lane >= 32) { s = ms[w][lane - 32]; r = mr[w][lane - 32]; }
+            wave_sort64(s, r, lane);
+        }
+        if (lane < a.kp) {
+            const size_t o = ((size_t)blockIdx.y * a.Q + q) * a.kp + lane;
+            a.out_s[o] = s;
+            a.out_r[o] = (r == SCAN_ROW_NONE) ? -1 : r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K11 stage 1b: merge the per-slab lists of one query into the query's top-k' (same filter +
 // compact machinery, entries streamed 64 per wave-instruction). One block per query.
 // Writes the page into cand[q][page_off .. page_off+kp) and advances the paging cursor.
@@ -415,6 +496,8 @@ struct RerankArgs {
     const float* qn;        // [Q, D] canonical-normalised queries
     const int32_t* cand;    // [Q][cand_stride]
     int cand_stride, ncand;
+    int group_mode;         // 1: cand holds GROUPMAX group ids, candidate c -> member c & 15 of group cand[c >> 4]
+    int64_t nrows;          // rows in the index (group members beyond it are skipped)
     const int64_t* labels;  // [N] row -> label
     int k;
     int64_t* out_labels;    // [Q, k]
@@ -436,8 +519,16 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
     for (int i = tid; i < npow; i += 256) { sd[i] = INFINITY; sl[i] = INT64_MAX; }
     __syncthreads();
     for (int c = wave; c < a.ncand; c += 4) {
-        const int row = a.cand[(size_t)q * a.cand_stride + c];
-        if (row < 0) continue;  // wave-uniform
+        int64_t row;
+        if (a.group_mode) {
+            const int g = a.cand[(size_t)q * a.cand_stride + (c >> 4)];
+            if (g < 0) continue;  // wave-uniform
+            row = groupmax_row(g, c & 15);
+            if (row >= a.nrows) continue;
+        } else {
+            row = a.cand[(size_t)q * a.cand_stride + c];
+            if (row < 0) continue;  // wave-uniform
+        }
         const T* rv = reinterpret_cast<const T*>(a.rows) + (size_t)row * a.D;
         double acc = 0.0;
         for (int d = lane; d < a.D; d += 64) acc = acc + (double)qv[d] * widen<T>(rv[d]);

@@ -86,6 +86,23 @@ def test_ties_break_by_label_and_duplicates(mods):
     np.testing.assert_array_equal(lab[0], np.arange(10))
 
 
+@pytest.mark.parametrize("N,D,Q,k", [(100, 128, 17, 10), (4097, 128, 33, 10), (30000, 512, 256, 10), (50000, 512, 100, 24), (9000, 768, 64, 3)])
+def test_batched_query_path_f16(mods, N, D, Q, k):
+    """Q > 16 on f16 rows takes the score-GEMM (group max) + select path; same bit-exact contract."""
+    FlatIndex, _, _, ro = mods
+    c = _corpus(N, D, seed=N + Q)
+    # plant near-duplicates of some queries so that several top hits share a 16-row group
+    q = _corpus(Q, D, seed=7 * N + Q)
+    rng = np.random.Generator(np.random.Philox(N))
+    for j in range(min(Q, 8)):
+        at = int(rng.integers(0, max(1, N - 40)))
+        c[at:at + 5] = q[j] + 0.05 * _corpus(5, D, seed=j + 1)
+    labels = np.arange(N, dtype=np.int64) + 11
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    _check(idx, ro, ro.normalize_rows(c, "f16"), labels, q, k)
+
+
 def test_adversarial_order_ascending_similarity(mods):
     """Rows sorted so every later row beats all earlier ones: the running top-k' list is rewritten constantly."""
     FlatIndex, _, _, ro = mods

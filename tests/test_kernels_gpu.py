@@ -23,11 +23,11 @@ def env():
     return torch, _lib, lib
 
 
-def _gemm(env, epi, A, W, out, bias=None, aux=None, p0=0, p1=0):
+def _gemm(env, epi, A, W, out, bias=None, aux=None, p0=0, p1=0, bm=0):
     torch, _lib, lib = env
     M, K = A.shape
     N = W.shape[0]
-    _lib.check(lib.mmiss_dbg_gemm(0, None, epi, 0, A.data_ptr(), W.data_ptr(), out.data_ptr(),
+    _lib.check(lib.mmiss_dbg_gemm(0, None, epi, bm, A.data_ptr(), W.data_ptr(), out.data_ptr(),
                                   bias.data_ptr() if bias is not None else None,
                                   aux.data_ptr() if aux is not None else None, M, N, K, p0, p1))
     torch.cuda.synchronize()
@@ -45,6 +45,29 @@ def test_gemm_f32_epilogue(env, M, N, K):
     # bf16 products are exact in fp32; only the accumulation order differs: 1e-4 relative to the row scale
     err = (out - ref).abs().max().item()
     assert err <= 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("bm,M", [(160, 320), (192, 384), (160, 1600), (192, 768)])
+def test_gemm_tile_heights(env, bm, M):
+    """The 160- and 192-row tiles (picked per shape to fill the CUs evenly) against the same fp32 reference."""
+    torch, _lib, lib = env
+    N, K = 256, 192
+    g = torch.Generator(device="cuda").manual_seed(bm + M)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().T
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _gemm(env, _lib.EPI_F32, A, W, out, bm=bm)
+    assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    x = x0.clone()
+    _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias, bm=bm)
+    assert torch.allclose(x, x0 + ref + bias, rtol=1e-5, atol=2e-4)
+    ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, ob, bias=bias, bm=bm)
+    r2 = ref + bias
+    assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
 
 
 def test_gemm_asymmetric_layout(env):
