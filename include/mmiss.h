@@ -197,6 +197,9 @@ int mmiss_merge_topk(int device, void* hip_stream, const float* dist, const int6
  * into buf (NUL-terminated, truncated to cap). Used by bench.py for the roofline object.
  */
 int mmiss_prof_enable(int on);
+/* restrict the bracketing to one kernel class and to every stride-th launch of it (kernel = NULL or "" lifts the
+ * restriction). Lets bench.py time the dominant kernel INSIDE its timed region at negligible cost. */
+int mmiss_prof_filter(const char* kernel, int stride);
 int mmiss_prof_reset(void);
 int mmiss_prof_read(char* buf, size_t cap);
 

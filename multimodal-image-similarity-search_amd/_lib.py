@@ -77,6 +77,7 @@ SIGNATURES = {
     "mmiss_blend": (_I, [_I, _P, _P, _P, C.c_double, _I32, _I32, _P]),
     "mmiss_merge_topk": (_I, [_I, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P]),
     "mmiss_prof_enable": (_I, [_I]),
+    "mmiss_prof_filter": (_I, [C.c_char_p, _I]),
     "mmiss_prof_reset": (_I, []),
     "mmiss_prof_read": (_I, [C.c_char_p, C.c_size_t]),
     # mmiss_debug.h
@@ -154,6 +155,10 @@ def current_stream_ptr(device=None):
 
 def prof_enable(on: bool) -> None:
     check(load().mmiss_prof_enable(1 if on else 0))
+
+
+def prof_filter(kernel=None, stride: int = 1) -> None:
+    check(load().mmiss_prof_filter(kernel.encode() if kernel else None, int(stride)))
 
 
 def prof_reset() -> None:

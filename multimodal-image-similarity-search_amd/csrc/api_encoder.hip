@@ -342,8 +342,15 @@ extern "C" int mmiss_encoder_destroy(mmiss_encoder* enc) {
 extern "C" int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream, int32_t use_own) {
     if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
     std::lock_guard<std::mutex> lk(enc->mu);
-    enc->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
-    enc->has_user_stream = use_own == 0;
+    hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
+    const bool next_user = use_own == 0;
+    if (next_user != enc->has_user_stream || (next_user && next != enc->user_stream)) {
+        // the handle's workspaces are shared by consecutive calls: drain the stream being left
+        MM_TRY(mmiss_use_device(enc->device));
+        MM_HIP(hipStreamSynchronize(enc->stream()));
+    }
+    enc->user_stream = next;
+    enc->has_user_stream = next_user;
     return MMISS_OK;
 }
 

@@ -160,8 +160,15 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
 extern "C" int mmiss_index_set_stream(mmiss_index* ix, void* hip_stream, int32_t use_own) {
     if (!ix) MM_FAIL(MMISS_ERR_ARG, "null index");
     std::lock_guard<std::mutex> lk(ix->mu);
-    ix->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
-    ix->has_user_stream = use_own == 0;
+    hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
+    const bool next_user = use_own == 0;
+    if (next_user != ix->has_user_stream || (next_user && next != ix->user_stream)) {
+        // the handle's workspaces are shared by consecutive calls: drain the stream being left
+        MM_TRY(mmiss_use_device(ix->device));
+        MM_HIP(hipStreamSynchronize(ix->stream()));
+    }
+    ix->user_stream = next;
+    ix->has_user_stream = next_user;
     return MMISS_OK;
 }
 
@@ -475,10 +482,11 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         while (npow < r.ncand) npow <<= 1;
         const int lds = npow * 12 + 16;
         MM_PROF("rerank", st, 2.0 * Q * r.ncand * D, (double)Q * r.ncand * D * ix->elt);
+        const int threads = r.ncand >= 256 ? 1024 : 256;  // one wave per candidate row: more waves hide the gather latency
         if (ix->dtype == MMISS_F16)
-            hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(Q), dim3(256), lds, st, r);
+            hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(Q), dim3(threads), lds, st, r);
         else
-            hipLaunchKernelGGL(rerank_kernel<float>, dim3(Q), dim3(256), lds, st, r);
+            hipLaunchKernelGGL(rerank_kernel<float>, dim3(Q), dim3(threads), lds, st, r);
         MM_HIP(hipGetLastError());
     }
     if (!out_dev) {

@@ -225,15 +225,20 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
 
-// tile height for a GEMM over M_pad rows (M_pad must be a multiple of the returned BM): the candidate that
-// wastes the fewest block slots of the 256 CU x 2 resident-block machine
+// Tile height for a GEMM over M_rows x N: the 256 CUs hold 2 blocks each (512 slots). A grid of <= 512 tiles runs
+// in one round, so fewer, taller tiles win as long as they still fit one round; past ~2 rounds the hardware's
+// dynamic dispatch smooths the tail and taller tiles win through operand reuse. Relative cost per row
+// (128: 1.00, 160: 0.93, 192: 0.89) fitted to tools/gemm_bench.py on the ViT-B/32 shapes (profiles/gemm_tiles_r01.txt).
 static inline int gemm_pick_bm(int64_t M_rows, int N) {
     int best = 128;
     double best_cost = 1e300;
-    for (int bm : {128, 160, 192}) {
-        const int64_t tiles = ((M_rows + bm - 1) / bm) * (N / GEMM_BN);
-        const int64_t rounds = (tiles + 511) / 512;
-        const double cost = (double)rounds * bm * (1.0 + 0.03 * (bm != 128));  // time ~ rounds x tile height
+    const int bms[3] = {128, 160, 192};
+    const double eff[3] = {1.00, 0.93, 0.89};
+    for (int v = 0; v < 3; ++v) {
+        const int bm = bms[v];
+        const double tiles = (double)((M_rows + bm - 1) / bm) * (N / GEMM_BN);
+        const double rounds = tiles <= 1024.0 ? (double)((int64_t)((tiles + 511.0) / 512.0)) : tiles / 512.0 + 0.5;
+        const double cost = rounds * bm * eff[v];
         if (cost < best_cost - 1e-9) { best_cost = cost; best = bm; }
     }
     return best;

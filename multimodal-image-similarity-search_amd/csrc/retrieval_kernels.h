@@ -506,7 +506,7 @@ struct RerankArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
+__global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // sort buffer: npow2 entries of (dist f32, label i64)
     int npow = 1;
@@ -516,9 +516,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const float* qv = a.qn + (size_t)q * a.D;
-    for (int i = tid; i < npow; i += 256) { sd[i] = INFINITY; sl[i] = INT64_MAX; }
+    const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
+    for (int i = tid; i < npow; i += nthreads) { sd[i] = INFINITY; sl[i] = INT64_MAX; }
     __syncthreads();
-    for (int c = wave; c < a.ncand; c += 4) {
+    for (int c = wave; c < a.ncand; c += nwaves) {
         int64_t row;
         if (a.group_mode) {
             const int g = a.cand[(size_t)q * a.cand_stride + (c >> 4)];
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
     // block bitonic sort ascending by (dist, label); NaN distances sort last
     for (int k = 2; k <= npow; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow; i += 256) {
+            for (int i = tid; i < npow; i += nthreads) {
                 const int p = i ^ j;
                 if (p > i) {
                     const float di = sd[i], dp = sd[p];
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs a) {
         }
     }
     int nvalid = 0;
-    for (int i = tid; i < a.k; i += 256) {
+    for (int i = tid; i < a.k; i += nthreads) {
         const bool ok = i < npow && sl[i] != INT64_MAX;
         a.out_labels[(size_t)q * a.k + i] = ok ? sl[i] : -1;
         a.out_dist[(size_t)q * a.k + i] = ok ? sd[i] : INFINITY;

@@ -79,6 +79,9 @@ struct ProfAcc {
 };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+std::string g_prof_filter;   // non-empty: only this kernel class is bracketed ...
+int g_prof_stride = 1;       // ... and only every stride-th launch of it
+long g_prof_seen = 0;
 std::vector<ProfRec> g_prof_pending;
 std::vector<hipEvent_t> g_prof_pool;
 std::map<std::string, ProfAcc> g_prof_acc;
@@ -130,6 +133,10 @@ ProfScope::ProfScope(const char* name, hipStream_t s, double flops, double bytes
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_on || g_prof_pending.size() > 200000) return;
+    if (!g_prof_filter.empty()) {
+        if (g_prof_filter != name) return;
+        if ((g_prof_seen++ % g_prof_stride) != 0) return;
+    }
     ProfRec r;
     r.name = name;
     r.e0 = prof_event();
@@ -152,6 +159,14 @@ ProfScope::~ProfScope() {
 extern "C" int mmiss_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_prof_filter(const char* kernel, int stride) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_filter = kernel ? kernel : "";
+    g_prof_stride = stride > 0 ? stride : 1;
+    g_prof_seen = 0;
     return MMISS_OK;
 }
 

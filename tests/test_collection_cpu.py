@@ -1,0 +1,78 @@
+"""Host bookkeeping of FlatCollection / PersistentClient (ids, metadata, persistence, chroma-like return shapes)
+with the numeric index replaced by an oracle-backed stand-in (no GPU here)."""
+import numpy as np
+import pytest
+
+from fakes import OracleIndex
+
+
+@pytest.fixture()
+def colmod(monkeypatch):
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd import collection
+
+    monkeypatch.setattr(collection, "FlatIndex", OracleIndex)
+    return collection
+
+
+def _vecs(n, d=128, seed=0):
+    return np.random.Generator(np.random.Philox(seed)).standard_normal((n, d), dtype=np.float32)
+
+
+def test_add_query_get_update_delete_roundtrip(colmod):
+    col = colmod.FlatCollection("t", metadata={"hnsw:space": "cosine"})
+    v = _vecs(6)
+    ids = [f"img_{i}" for i in range(6)]
+    metas = [{"filename": f"{i}.jpg", "n": i} for i in range(6)]
+    for i in range(6):  # the reference adds one image at a time (main.py:735-740), embeddings as python lists
+        col.add(ids=[ids[i]], embeddings=[v[i].tolist()], metadatas=[metas[i]], documents=[f"caption {i}"])
+    assert col.count() == 6
+    res = col.query(query_embeddings=[v[2].tolist()], n_results=1000, include=["metadatas", "distances"])
+    assert res["ids"][0][0] == "img_2" and len(res["ids"][0]) == 6  # n_results > count is not an error
+    assert res["distances"][0][0] < 1e-6 and res["distances"][0] == sorted(res["distances"][0])
+    assert res["metadatas"][0][0]["n"] == 2 and res["documents"] is None
+    got = col.get(ids=["img_3", "missing"], include=["metadatas"])
+    assert got["ids"] == ["img_3"] and got["metadatas"][0]["filename"] == "3.jpg"
+    assert col.get(include=[])["ids"] == ids and col.get(include=[])["metadatas"] is None
+    col.update(ids=["img_3"], metadatas=[{"filter_results_json": "{}"}])
+    assert col.get(ids=["img_3"])["metadatas"][0] == {"filename": "3.jpg", "n": 3, "filter_results_json": "{}"}
+    with pytest.raises(colmod.DuplicateIDError):
+        col.add(ids=["img_1"], embeddings=[v[1].tolist()])
+    col.delete(ids=["img_2", "nope"])
+    assert col.count() == 5 and "img_2" not in col.get(include=[])["ids"]
+    res = col.query(query_embeddings=[v[2].tolist()], n_results=3)
+    assert "img_2" not in res["ids"][0] and len(res["ids"][0]) == 3
+    col.delete()
+    assert col.count() == 0 and col.query(query_embeddings=[v[0].tolist()], n_results=5)["ids"] == [[]]
+
+
+def test_rejects_non_cosine_and_dimension_mismatch(colmod):
+    with pytest.raises(ValueError):
+        colmod.FlatCollection("x", metadata={"hnsw:space": "l2"})
+    col = colmod.FlatCollection("t")
+    col.add(ids=["a"], embeddings=_vecs(1, 128))
+    with pytest.raises(ValueError):
+        col.add(ids=["b"], embeddings=_vecs(1, 256))
+    with pytest.raises(ValueError):
+        col.query(query_embeddings=_vecs(1, 256), n_results=1)
+
+
+def test_persistent_client_reopens_collection(colmod, tmp_path):
+    client = colmod.PersistentClient(path=str(tmp_path))
+    assert client.list_collections() == []
+    col = client.create_collection("image-match", metadata={"hnsw:space": "cosine"})
+    v = _vecs(4)
+    col.add(ids=list("abcd"), embeddings=v, metadatas=[{"i": i} for i in range(4)], documents=list("wxyz"))
+    col.delete(ids=["b"])
+    again = colmod.PersistentClient(path=str(tmp_path))
+    assert again.list_collections() == ["image-match"]
+    col2 = again.get_collection("image-match")
+    assert col2.count() == 3 and col2.get(include=["documents"])["documents"] == ["w", "y", "z"]
+    r1 = col.query(query_embeddings=v[3:4], n_results=3)
+    r2 = col2.query(query_embeddings=v[3:4], n_results=3)
+    assert r1["ids"] == r2["ids"] and r1["distances"] == r2["distances"]
+    col2.add(ids=["e"], embeddings=_vecs(1, seed=9))  # labels keep increasing after a reload
+    with pytest.raises(ValueError):
+        again.create_collection("image-match")
+    with pytest.raises(ValueError):
+        again.get_collection("other")

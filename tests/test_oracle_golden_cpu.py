@@ -1,0 +1,85 @@
+"""The numpy oracle against the committed golden vectors (tests/golden/, produced by tools/make_goldens.py with
+transformers' CLIPModel following the reference's call sequence, and by an independent float64 brute force)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import clip_oracle as co
+from oracle import retrieval_oracle as ro
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cos(a, b):
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def test_tiny_clip_embeddings_and_intermediates():
+    g = np.load(os.path.join(G, "clip_tiny.npz"))
+    s = co.TINY
+    W = co.init_weights(s, int(g["weight_seed"]))
+    px = np.random.Generator(np.random.Philox(int(g["pixel_seed"]))).standard_normal((8, 3, s.v_image, s.v_image), dtype=np.float32)
+    taps = {}
+    raw = co.image_features(px, W, s, taps)
+    np.testing.assert_allclose(raw, g["image_raw"], atol=2e-5)
+    np.testing.assert_allclose(co.l2_normalize(raw), g["image"], atol=2e-6)
+    np.testing.assert_allclose(taps[0], g["vis_hidden_0"], atol=2e-5)
+    np.testing.assert_allclose(taps[1], g["vis_hidden_1"], atol=5e-5)
+    np.testing.assert_allclose(taps[s.v_layers], g["vis_hidden_last"], atol=5e-5)
+    np.testing.assert_allclose(co.embed_texts(g["ids"], W, s), g["text"], atol=2e-6)
+
+
+def test_b32_clip_embeddings():
+    g = np.load(os.path.join(G, "clip_b32.npz"))
+    s = co.VIT_B32
+    W = co.init_weights(s, int(g["weight_seed"]))
+    px = np.random.Generator(np.random.Philox(int(g["pixel_seed"]))).standard_normal((4, 3, 224, 224), dtype=np.float32)
+    img = co.embed_images(px, W, s)
+    txt = co.embed_texts(g["ids"], W, s)
+    assert (1 - _cos(img, g["image"])).max() < 1e-6
+    assert (1 - _cos(txt, g["text"])).max() < 1e-6
+    np.testing.assert_allclose(img, g["image"], atol=5e-6)
+
+
+def test_drill_set_config1():
+    """BASELINE configs[0]: the reference's 6 sample images through preprocess -> encode -> cosine, seeded weights."""
+    g = np.load(os.path.join(G, "drill_set.npz"))
+    s = co.VIT_B32
+    W = co.init_weights(s, 0)
+    assert float(g["hf_pixel_max_abs_diff"]) < 1e-6  # oracle preprocessing == HF CLIPImageProcessor on these files
+    px = co.normalize_u8(g["crops_u8"])
+    img = co.embed_images(px, W, s)
+    assert (1 - _cos(img, g["image"])).max() < 1e-6
+    np.testing.assert_allclose(img @ img.T, g["cosine"], atol=1e-5)
+    txt = co.embed_texts(g["query_ids"], W, s)
+    np.testing.assert_allclose(txt @ img.T, g["text_image_cosine"], atol=1e-5)
+    # exact cosine query over the 6 embeddings = chromadb's brute-force regime (< 100 rows)
+    labels = np.arange(6, dtype=np.int64)
+    lab, dist, cnt = ro.query(txt, ro.normalize_rows(img), labels, 6)
+    expect = np.argsort(-(g["text_image_cosine"][0]), kind="stable")
+    assert list(lab[0]) == list(expect)
+    np.testing.assert_allclose(dist[0], 1 - g["text_image_cosine"][0][expect], atol=1e-5)
+
+
+def test_preprocessing_matches_hf_processor_fixture():
+    from PIL import Image
+
+    g = np.load(os.path.join(G, "preprocess.npz"))
+    for key in ("wide", "tall"):
+        got = co.preprocess_image(Image.fromarray(g[f"{key}_u8"]))
+        np.testing.assert_allclose(got, g[f"{key}_pixels"], atol=1e-6)
+
+
+def test_retrieval_matches_independent_float64_bruteforce():
+    g = np.load(os.path.join(G, "retrieval.npz"))
+    N, D = int(g["N"]), int(g["D"])
+    corpus = np.random.Generator(np.random.Philox(int(g["corpus_seed"]))).standard_normal((N, D), dtype=np.float32)
+    labels = np.arange(N, dtype=np.int64)
+    lab, dist, cnt = ro.query(g["queries"], ro.normalize_rows(corpus, "f32"), labels, 10)
+    np.testing.assert_array_equal(lab, g["top10_ids"])
+    np.testing.assert_allclose(dist, g["top10_dist"], atol=2e-7)
+    # fp16 storage moves distances by ~1e-4 but (on this corpus) not the top-10 membership
+    lab16, dist16, _ = ro.query(g["queries"], ro.normalize_rows(corpus, "f16"), labels, 10)
+    assert np.mean(lab16 == g["top10_ids"]) > 0.9
+    np.testing.assert_allclose(dist16, g["top10_dist"], atol=5e-4)

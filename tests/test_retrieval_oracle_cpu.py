@@ -1,0 +1,76 @@
+"""The retrieval oracle: numpy restatement == plain-C restatement bit for bit, both close to a straightforward
+float64 evaluation; tie-break, padding, blend and shard-merge semantics."""
+import numpy as np
+import pytest
+
+from oracle import retrieval_oracle as ro
+
+
+def _rand(n, d, seed):
+    return np.random.Generator(np.random.Philox(seed)).standard_normal((n, d), dtype=np.float32)
+
+
+@pytest.fixture(scope="module")
+def rc():
+    from oracle import retrieval_oracle_c as rc
+
+    rc._lib()
+    return rc
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("N,D,Q,k", [(1, 128, 1, 1), (50, 128, 3, 10), (3000, 512, 5, 10), (700, 768, 2, 100)])
+def test_numpy_and_c_oracles_agree_bitwise(rc, dtype, N, D, Q, k):
+    c, q = _rand(N, D, N + D), _rand(Q, D, Q + k)
+    labels = np.arange(N, dtype=np.int64) * 7 + 3
+    a, b = ro.normalize_rows(c, dtype), rc.normalize_rows(c, dtype)
+    assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    for x, y in zip(ro.query(q, a, labels, k), rc.query(q, b, labels, k)):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_canonical_distance_is_close_to_plain_float64():
+    c, q = _rand(2000, 512, 1), _rand(4, 512, 2)
+    d = ro.distances(q, ro.normalize_rows(c))
+    c64, q64 = c.astype(np.float64), q.astype(np.float64)
+    ref = 1 - (q64 @ c64.T) / (np.linalg.norm(q64, axis=1)[:, None] * np.linalg.norm(c64, axis=1)[None])
+    np.testing.assert_allclose(d, ref, atol=2e-7)
+
+
+def test_ties_break_by_label_and_short_results_are_padded():
+    base = _rand(10, 128, 5)
+    c = np.concatenate([base, base, base])
+    labels = np.array(list(range(100, 110)) + list(range(10)) + list(range(50, 60)), dtype=np.int64)
+    order = np.argsort(labels)
+    c, labels = c[order], labels[order]
+    lab, dist, cnt = ro.query(base[:2], ro.normalize_rows(c), labels, 3)
+    assert list(lab[0]) == [0, 50, 100] and list(lab[1]) == [1, 51, 101]
+    assert dist[0, 0] == dist[0, 1] == dist[0, 2]
+    lab, dist, cnt = ro.query(base[:1], ro.normalize_rows(c[:4]), labels[:4], 10)
+    assert cnt[0] == 4 and (lab[0, 4:] == -1).all() and np.isinf(dist[0, 4:]).all()
+    lab, dist, cnt = ro.query(base[:1], ro.normalize_rows(c[:0].reshape(0, 128)), labels[:0], 5)
+    assert cnt[0] == 0 and (lab == -1).all()
+
+
+def test_similarity_conversion_matches_reference_formula():
+    assert ro.similarity_from_distance(np.array([0.0, 1.0, 2.0], np.float32)) == [1.0, 0.5, 0.0]
+
+
+def test_blend_close_to_reference_numpy_formula_and_c(rc):
+    from oracle import clip_oracle as co
+
+    i, t = _rand(9, 512, 11), _rand(9, 512, 12)
+    for w in (0.5, 0.25, 0.0, 1.0, -0.3):
+        np.testing.assert_array_equal(ro.blend(i, t, w).view(np.uint32), rc.blend(i, t, w).view(np.uint32))
+        np.testing.assert_allclose(ro.blend(i, t, w), co.blend_reference(i, t, w), atol=1e-6)
+
+
+def test_merge_shards_equals_unsharded():
+    c, q = _rand(900, 128, 21), _rand(4, 128, 22)
+    labels = np.arange(900, dtype=np.int64)
+    stored = ro.normalize_rows(c, "f16")
+    full = ro.query(q, stored, labels, 10)
+    parts = [ro.query(q, stored[s::3], labels[s::3], 10) for s in range(3)]
+    ml, md, mc = ro.merge_shards(np.stack([p[1] for p in parts]), np.stack([p[0] for p in parts]), 10)
+    np.testing.assert_array_equal(ml, full[0])
+    np.testing.assert_array_equal(md, full[1])

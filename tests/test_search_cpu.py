@@ -1,0 +1,82 @@
+"""The reference-facing wrappers (search_similar / search_by_text / search_multimodal / process_image /
+generate_clip_embedding) with model, processor and collection replaced by oracle-backed stand-ins."""
+import numpy as np
+import pytest
+
+from fakes import OracleEncoder, OracleIndex
+from oracle import clip_oracle as co
+
+
+class _Proc:
+    def __init__(self, shape):
+        self.shape = shape
+
+    def preprocess_images(self, images):
+        return np.stack([np.asarray(im, np.float32) for im in images])
+
+    def tokenize(self, texts):
+        return np.stack([co.synthetic_text_ids(1, self.shape.t_ctx, self.shape.t_vocab, self.shape.eos_token_id, seed=len(t))[0] for t in texts])
+
+
+@pytest.fixture()
+def env(monkeypatch):
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd import collection, index, search, utils
+
+    monkeypatch.setattr(collection, "FlatIndex", OracleIndex)
+    from oracle import retrieval_oracle as ro
+
+    monkeypatch.setattr(search, "blend", lambda i, t, w: ro.blend(i, t, w))
+    enc = OracleEncoder(co.TINY)
+    utils.set_clip_model(enc, _Proc(co.TINY))
+    col = collection.FlatCollection("t")
+    search.set_collection(col)
+    yield search, utils, col, enc
+    utils.set_clip_model(None, None)
+    search.set_collection(None)
+
+
+def _img(seed):
+    s = co.TINY
+    return np.random.Generator(np.random.Philox(seed)).standard_normal((3, s.v_image, s.v_image), dtype=np.float32)
+
+
+def test_generate_clip_embedding_shapes_and_norms(env):
+    search, utils, col, enc = env
+    r = utils.generate_clip_embedding(image=_img(1), text="red drill")
+    assert r["image"].shape == (1, co.TINY.proj_dim) and r["text"].shape == (1, co.TINY.proj_dim)
+    assert r["image"].dtype == np.float32
+    assert abs(np.linalg.norm(r["image"][0]) - 1) < 1e-5 and abs(np.linalg.norm(r["text"][0]) - 1) < 1e-5
+    assert utils.generate_clip_embedding() == {}
+
+
+def test_process_then_search_paths(env):
+    search, utils, col, enc = env
+    imgs = [_img(i) for i in range(5)]
+    for i, im in enumerate(imgs):
+        meta, created = search.process_image(im, f"img_{i}", {"id": f"img_{i}", "filename": f"{i}.png", "url": f"/u/{i}"})
+        assert created
+    meta, created = search.process_image(imgs[0], "img_0")
+    assert not created and meta["filename"] == "0.png"  # duplicate -> existing metadata, caller answers 409
+    emb = utils.generate_clip_embedding(image=imgs[3])["image"][0]
+    res = search.search_similar(emb, limit=0)  # "All" -> 1000
+    assert len(res) == 5 and res[0]["id"] == "img_3"
+    assert abs(res[0]["similarity_score"] - 1.0) < 1e-6
+    assert res[0]["url"] == "/u/3" and res[0]["thumbnail_url"] == "/static/processed/img_3.png"
+    scores = [r["similarity_score"] for r in res]
+    assert scores == sorted(scores, reverse=True) and all(-1e-6 <= s <= 1.0 + 1e-6 for s in scores)
+    assert len(search.search_similar(emb, limit=2)) == 2
+    assert len(search.search_by_text("a red drill", limit=3)) == 3
+    mm = search.search_multimodal(imgs[1], "drill", weight_image=1.0, limit=1)
+    assert mm[0]["id"] == "img_1"
+    batch = search.search_similar_batch(np.stack([utils.generate_clip_embedding(image=im)["image"][0] for im in imgs]), limit=1)
+    assert [b[0]["id"] for b in batch] == [f"img_{i}" for i in range(5)]
+    assert search.process_images(imgs, [f"img_{i}" for i in range(5)]) == 0
+
+
+def test_errors_become_empty_lists_like_the_reference(env):
+    search, utils, col, enc = env
+    assert search.search_similar(np.zeros(7, np.float32), limit=5) == []  # wrong dimension -> logged, []
+    utils.set_clip_model(None, None)
+    assert search.search_by_text("x") == []  # no weights configured -> load_clip_model raises -> []
+    assert search.search_multimodal(_img(0), "x") == []
