@@ -2,6 +2,7 @@
 // Launch sequence per layer follows HF:modeling_clip.py:353-383 (pre-LN transformer block).
 #include "common.h"
 #include "gemm_bf16.h"
+#include "gemm_bf16_256.h"
 #include "encoder_kernels.h"
 #include <map>
 #include <set>
@@ -20,6 +21,18 @@ __global__ void convert_2d_bf16_kernel(const float* __restrict__ src, uint16_t* 
     }
 }
 
+// dst row r = src row rowmap[r]; rows of row_bytes (a multiple of 16) — compacts the pooled rows for the last layer
+__global__ void gather_rows16_kernel(const char* __restrict__ src, const int32_t* __restrict__ rowmap,
+                                     char* __restrict__ dst, int n, int row_bytes) {
+    const int chunks = row_bytes >> 4;
+    const int64_t total = (int64_t)n * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / chunks), c = (int)(i - (int64_t)r * chunks);
+        *reinterpret_cast<u32x4*>(dst + (size_t)r * row_bytes + (size_t)c * 16) =
+            *reinterpret_cast<const u32x4*>(src + (size_t)rowmap[r] * row_bytes + (size_t)c * 16);
+    }
+}
+
 struct LayerW {
     DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, ln2g, ln2b, w1, b1, w2, b2;
 };
@@ -33,6 +46,8 @@ struct Tower {
     // workspaces (lazily allocated for max_batch)
     int ws_batch = 0;
     DevBuf x, h, qkv, ctx, u, pooled, proj_out, pool_row, out_stage, taps;
+    DevBuf xc, hc, ctxc, uc;  // compact [Bp, *] buffers of the pooled rows (last-layer pruning)
+    bool pooled_compact = false;
     int last_B = 0, last_T = 0;
     int64_t tap_stride = 0;  // floats per recorded tap
 };
@@ -148,6 +163,10 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     MM_TRY(alloc_zero(tw.proj_out, (size_t)Bp * proj_dim * 4));
     MM_TRY(alloc_zero(tw.pool_row, (size_t)max_batch * 4));
     MM_TRY(alloc_zero(tw.out_stage, (size_t)max_batch * proj_dim * 4));
+    MM_TRY(alloc_zero(tw.xc, (size_t)Bp * d * 4));
+    MM_TRY(alloc_zero(tw.hc, (size_t)Bp * d * 2));
+    MM_TRY(alloc_zero(tw.ctxc, (size_t)Bp * d * 2));
+    MM_TRY(alloc_zero(tw.uc, (size_t)Bp * tw.mlp * 2));
     if (e->record_taps) {
         tw.tap_stride = Mp * d;
         MM_TRY(alloc_zero(tw.taps, (size_t)(tw.layers + 1) * tw.tap_stride * 4));
@@ -170,6 +189,11 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         return MMISS_OK;
     };
     MM_TRY(tap(0));
+    // Only the pooled row of every item (token 0 / first EOS) leaves the last layer (HF:modeling_clip.py:650-651,
+    // 561-581), and rows do not mix after the attention: out-proj, LN2 and the MLP of the LAST layer run on those B
+    // rows only (compacted). Kept off while taps are recorded so the tests can compare every row of every layer.
+    const bool prune = !e->record_taps;
+    tw.pooled_compact = false;
     for (int l = 0; l < tw.layers; ++l) {
         LayerW& L = tw.L[l];
         MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
@@ -178,6 +202,28 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         ep.out = tw.qkv.p; ep.bias = L.bqkv.as<float>(); ep.ldo = 3 * d; ep.m_valid = M;
         MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
         MM_TRY(launch_attention(st, tw.qkv.p, tw.ctx.p, B, tw.T, tw.heads, causal));
+        if (prune && l == tw.layers - 1) {
+            const int Bp = (int)round_up(B, 128);
+            const int grid = (B * d / 4 + 255) / 256;
+            hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid), dim3(256), 0, st, tw.ctx.as<char>(),
+                               tw.pool_row.as<int32_t>(), tw.ctxc.as<char>(), B, d * 2);
+            hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid), dim3(256), 0, st, tw.x.as<char>(),
+                               tw.pool_row.as<int32_t>(), tw.xc.as<char>(), B, d * 4);
+            MM_HIP(hipGetLastError());
+            ep = GemmEpi{};
+            ep.out = tw.xc.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = B;
+            MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, 128, tw.ctxc.p, L.wo.p, ep, Bp, d, d));
+            MM_TRY(launch_layernorm(st, tw.xc.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.hc.p, true, nullptr,
+                                    B, d, eps));
+            ep = GemmEpi{};
+            ep.out = tw.uc.p; ep.bias = L.b1.as<float>(); ep.ldo = tw.mlp; ep.m_valid = B;
+            MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, 128, tw.hc.p, L.w1.p, ep, Bp, tw.mlp, d));
+            ep = GemmEpi{};
+            ep.out = tw.xc.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = B;
+            MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, 128, tw.uc.p, L.w2.p, ep, Bp, d, tw.mlp));
+            tw.pooled_compact = true;
+            break;
+        }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = M;
         MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
@@ -198,8 +244,12 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
 int run_head(mmiss_encoder* e, Tower& tw, int B, float* out_dev, hipStream_t st) {
     const int d = tw.hidden, P = e->cfg.proj_dim;
     const int Bp = (int)round_up(B, 128);
-    MM_TRY(launch_layernorm(st, tw.x.as<float>(), tw.lnf_g.as<float>(), tw.lnf_b.as<float>(), tw.pooled.p, true,
-                            tw.pool_row.as<int32_t>(), B, d, e->cfg.ln_eps));
+    if (tw.pooled_compact)  // the last layer already compacted the pooled rows into xc
+        MM_TRY(launch_layernorm(st, tw.xc.as<float>(), tw.lnf_g.as<float>(), tw.lnf_b.as<float>(), tw.pooled.p, true,
+                                nullptr, B, d, e->cfg.ln_eps));
+    else
+        MM_TRY(launch_layernorm(st, tw.x.as<float>(), tw.lnf_g.as<float>(), tw.lnf_b.as<float>(), tw.pooled.p, true,
+                                tw.pool_row.as<int32_t>(), B, d, e->cfg.ln_eps));
     GemmEpi ep{};
     ep.out = tw.proj_out.p; ep.ldo = P; ep.m_valid = B;
     MM_TRY(launch_gemm(st, MMISS_EPI_F32, 0, tw.pooled.p, tw.proj.p, ep, Bp, P, d));
@@ -227,9 +277,9 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
     // pre_layrnorm, in place on the fp32 residual stream (HF:modeling_clip.py:640)
     MM_TRY(launch_layernorm(st, tw.x.as<float>(), e->pre_g.as<float>(), e->pre_b.as<float>(), tw.x.p, false, nullptr,
                             B * tw.T, d, e->cfg.ln_eps));
-    MM_TRY(run_layers(e, tw, B, false, st));
     hipLaunchKernelGGL(vision_pool_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, tw.pool_row.as<int32_t>(), B,
                        tw.T);
+    MM_TRY(run_layers(e, tw, B, false, st));
     MM_TRY(run_head(e, tw, B, out_dev, st));
     tw.last_B = B;
     tw.last_T = tw.T;
@@ -538,6 +588,7 @@ extern "C" int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant
     MM_TRY(mmiss_use_device(device));
     GemmEpi ep{};
     ep.out = out; ep.bias = bias; ep.aux = aux; ep.ldo = N; ep.m_valid = M; ep.p0 = p0; ep.p1 = p1;
+    if (variant == 256) return launch_gemm256(reinterpret_cast<hipStream_t>(hip_stream), epi, A, W, ep, M, N, K);
     return launch_gemm(reinterpret_cast<hipStream_t>(hip_stream), epi, variant, A, W, ep, M, N, K);
 }
 
@@ -551,9 +602,13 @@ extern "C" int mmiss_dbg_gemm_time(int device, int epi, int variant, const void*
     hipEvent_t e0, e1;
     MM_HIP(hipEventCreate(&e0));
     MM_HIP(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) MM_TRY(launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K));
+    auto run = [&]() -> int {
+        if (variant == 256) return launch_gemm256(nullptr, epi, A, W, ep, M, N, K);
+        return launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K);
+    };
+    for (int i = 0; i < 3; ++i) MM_TRY(run());
     MM_HIP(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) MM_TRY(launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K));
+    for (int i = 0; i < iters; ++i) MM_TRY(run());
     MM_HIP(hipEventRecord(e1, nullptr));
     MM_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

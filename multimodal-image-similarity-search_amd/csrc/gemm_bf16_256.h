@@ -1,0 +1,240 @@
+// gemm_bf16_256.h — 256x256x64 tile, 8-wave, phase-pipelined variant of the 16-bit MFMA GEMM of gemm_bf16.h
+// (same contract: C[M,N] = A[M,K] * W[N,K]^T + fused epilogue), for the wide GEMMs of the towers (QKV, FC1).
+//
+// Why a second structure: the 128-row kernel stages 32-40 KB per 32 MFMAs and drains its loads at one barrier per
+// K-tile; its main loop tops out near 40 % of the MFMA peak (profiles/r01_gemm_pmc_summary.csv: 43 % of the wave
+// cycles are issue stalls, 30 % waits). Here (guide §5 "256² 8-phase template" ideas, own schedule):
+//   * 8 waves = 2 (M) x 4 (N), each owning 128 x 64 of the output -> 64 MFMAs per wave per K-tile for 8 LDS-DMA
+//     loads (1:8 instead of 1:4) and 24 ds_read_b128 (instead of 32 per 64);
+//   * a K-tile is consumed in 4 phases, one 64x32 quadrant of the wave's output each, in the order
+//     (m0,n0) (m0,n1) (m1,n1) (m1,n0); the LDS image of a K-tile is 4 slots of 16 KB (the m0 / m1 halves of every
+//     wave's activation rows, the n0 / n1 halves of every wave's weight rows), and a slot is dead as soon as its
+//     quadrant phase has read it: its NEXT-BUT-ONE K-tile is staged into it two phases later;
+//   * so 5 slot loads (10 global_load_lds per wave) are always in flight across the phase barriers, retired by a
+//     COUNTED s_waitcnt vmcnt(10) — never 0 in steady state — and raw s_barrier (a __syncthreads() would drain them);
+//   * reads of a slot happen one phase after the barrier that follows the wait retiring it (RAW), restaging at least
+//     one barrier after its last read (WAR).
+#pragma once
+#include "gemm_bf16.h"
+
+#define G256_SLOT 16384
+#define G256_LDS (8 * G256_SLOT)
+
+template <typename IN, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M,
+                                                         int N, int K, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename MfmaIn<IN>::frag frag;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nbm = M >> 8, nbn = N >> 8;
+    const int nwg = nbm * nbn;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    int bm, bn;
+    if (ep.m_fast) { bn = wg / nbm; bm = wg - bn * nbm; }
+    else           { bm = wg / nbn; bn = wg - bm * nbn; }
+    const IN* Ab = A + (size_t)bm * 256 * K;
+    const IN* Wb = W + (size_t)bn * 256 * K;
+    const int nt = K / GEMM_BK;
+
+    // ---- staging: slot `which` (0 = A m0, 1 = A m1, 2 = W n0, 3 = W n1) of buffer b with K-tile kt.
+    // A wave stages slot rows 16*wave .. 16*wave+15 (two 8-row LDS-DMA pieces). Slot row r of an A slot is the
+    // activation row (r>>6)*128 + mq*64 + (r&63) of the tile; of a W slot the weight row (r>>5)*64 + nq*32 + (r&31).
+    const int r_in = lane >> 3, p = lane & 7;
+    const int src_chunk = (p ^ r_in) * 8;  // XOR swizzle on the source; the LDS image stays lane-linear
+    const int a_row0 = (wave >> 2) * 128 + (wave & 3) * 16 + r_in;  // + mq*64 + i*8
+    const int w_row0 = (wave >> 1) * 64 + (wave & 1) * 16 + r_in;   // + nq*32 + i*8
+    auto stage = [&](int which, int b, int kt) {
+        if (kt >= nt) return;
+        char* dst = smem + (b * 4 + which) * G256_SLOT + wave * 2048;
+        const size_t koff = (size_t)kt * GEMM_BK + src_chunk;
+        if (which < 2) {
+            const IN* src = Ab + (size_t)(a_row0 + which * 64) * K + koff;
+            glds16(src, dst);
+            glds16(src + (size_t)8 * K, dst + 1024);
+        } else {
+            const IN* src = Wb + (size_t)(w_row0 + (which - 2) * 32) * K + koff;
+            glds16(src, dst);
+            glds16(src + (size_t)8 * K, dst + 1024);
+        }
+    };
+
+    frag am[4][2];     // activation fragments of the current m-half: [m sub-tile][k step]
+    frag wq[2][2][2];  // weight fragments of both n-halves:          [n half][n sub-tile][k step]
+    f32x4 acc[4][8];   // [i = nq*2 + nf][j = mq*4 + mf]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets inside a slot (row*128 + swizzled 16-byte chunk), k step 0; step 1 = chunk + 4
+    int a_off[4][2], w_off[2][2];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int row = wm * 64 + mf * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a_off[mf][s] = row * 128 + (((4 * s + fg) ^ (row & 7)) << 4);
+    }
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+        const int row = wn * 32 + nf * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w_off[nf][s] = row * 128 + (((4 * s + fg) ^ (row & 7)) << 4);
+    }
+
+#define G256_READ_A(b, mq)                                                                          \
+    {                                                                                               \
+        const char* sl = smem + ((b) * 4 + (mq)) * G256_SLOT;                                       \
+        _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) {                                          \
+            am[mf][0] = *reinterpret_cast<const frag*>(sl + a_off[mf][0]);                          \
+            am[mf][1] = *reinterpret_cast<const frag*>(sl + a_off[mf][1]);                          \
+        }                                                                                           \
+    }
+#define G256_READ_W(b, nq)                                                                          \
+    {                                                                                               \
+        const char* sl = smem + ((b) * 4 + 2 + (nq)) * G256_SLOT;                                   \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                          \
+            wq[nq][nf][0] = *reinterpret_cast<const frag*>(sl + w_off[nf][0]);                      \
+            wq[nq][nf][1] = *reinterpret_cast<const frag*>(sl + w_off[nf][1]);                      \
+        }                                                                                           \
+    }
+#define G256_MMA(mq, nq)                                                                            \
+    {                                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                              \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
+            _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                        \
+                _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                    \
+                    acc[(nq) * 2 + nf][(mq) * 4 + mf] =                                             \
+                        MfmaIn<IN>::mma(wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf]); \
+        __builtin_amdgcn_s_setprio(0);                                                              \
+    }
+#define G256_WAIT(full)                                                  \
+    {                                                                    \
+        if (full) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
+    }
+#define G256_BARRIER()                         \
+    {                                          \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    }
+
+    // ---- prologue: K-tile 0 completely, K-tile 1 except its m1 slot (staged by phase 0 of K-tile 0)
+    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+    stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1);
+    G256_WAIT(nt >= 2);  // retires A m0 / W n0 of K-tile 0 (the 5 younger slot loads may still fly)
+    G256_BARRIER();
+
+    for (int t = 0; t < nt; ++t) {
+        const int b = t & 1;
+        const bool full = (t + 2 < nt);  // the counted wait assumes the loads of K-tile t+2 were issued
+        // phase 0: quadrant (m0, n0)
+        G256_READ_A(b, 0);
+        G256_READ_W(b, 0);
+        stage(1, b ^ 1, t + 1);
+        G256_MMA(0, 0);
+        G256_WAIT(full);
+        G256_BARRIER();
+        // phase 1: quadrant (m0, n1)
+        G256_READ_W(b, 1);
+        stage(0, b, t + 2);
+        G256_MMA(0, 1);
+        G256_WAIT(full);
+        G256_BARRIER();
+        // phase 2: quadrant (m1, n1)
+        G256_READ_A(b, 1);
+        stage(2, b, t + 2);
+        G256_MMA(1, 1);
+        G256_BARRIER();
+        // phase 3: quadrant (m1, n0) — operands already in registers
+        stage(3, b, t + 2);
+        G256_MMA(1, 0);
+        G256_WAIT(full);
+        G256_BARRIER();
+    }
+#undef G256_READ_A
+#undef G256_READ_W
+#undef G256_MMA
+#undef G256_WAIT
+#undef G256_BARRIER
+
+    // acc[i][j][reg] = C[m = m_base + j*16][n = n_base + i*16 + reg]
+    const int m_base = bm * 256 + wm * 128 + fr;
+    const int n_base = bn * 256 + wn * 64 + 4 * fg;
+    f32x4 bias[4];
+    if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + n_base + i * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = m_base + j * 16;
+        if (m >= ep.m_valid) continue;
+        if constexpr (EPI == MMISS_EPI_F32) {
+            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = acc[i][j];
+        } else if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16) {
+            uint16_t* row = reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_base;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = acc[i][j][r] + bias[i][r];
+                    if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[r] = quick_gelu(y[r]);
+                }
+                u32x2 pk;
+                pk[0] = pack_bf16x2(y[0], y[1]);
+                pk[1] = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<u32x2*>(row + i * 16) = pk;
+            }
+        } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
+            f32x4 x[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + i * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = x[i] + acc[i][j] + bias[i];
+        }
+    }
+}
+
+template <typename IN, int EPI>
+static int launch_gemm256_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<IN, EPI>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+        attr_done = true;
+    }
+    const int nwg = (M / 256) * (N / 256);
+    hipLaunchKernelGGL((gemm256_kernel<IN, EPI>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                       reinterpret_cast<const IN*>(W), M, N, K, ep);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+// bf16 GEMM on the 256x256 tile: M, N multiples of 256, K a multiple of 64; epilogues F32 / BIAS_BF16 /
+// BIAS_QGELU_BF16 / BIAS_RESID_F32.
+static int launch_gemm256(hipStream_t st, int epi, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % GEMM_BK))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256: M=%d N=%d K=%d must be multiples of 256/256/%d", M, N, K, GEMM_BK);
+    static const char* names[] = {"gemm_bf16_f32", "gemm_bf16_bias", "gemm_bf16_bias_qgelu", "gemm_bf16_bias_resid"};
+    if (epi < 0 || epi > 3) MM_FAIL(MMISS_ERR_ARG, "gemm256: bad epilogue %d", epi);
+    const int out_elt = (epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16) ? 2 : 4;
+    const int mv = ep.m_valid < M ? ep.m_valid : M;
+    const double bytes = 2.0 * ((double)mv * K + (double)N * K) +
+                         (double)out_elt * mv * N * (epi == MMISS_EPI_BIAS_RESID_F32 ? 2 : 1);
+    MM_PROF(names[epi], st, gemm_flops(mv, N, K), bytes);
+    switch (epi) {
+        case MMISS_EPI_F32: return launch_gemm256_inst<__bf16, MMISS_EPI_F32>(st, A, W, ep, M, N, K);
+        case MMISS_EPI_BIAS_BF16: return launch_gemm256_inst<__bf16, MMISS_EPI_BIAS_BF16>(st, A, W, ep, M, N, K);
+        case MMISS_EPI_BIAS_QGELU_BF16: return launch_gemm256_inst<__bf16, MMISS_EPI_BIAS_QGELU_BF16>(st, A, W, ep, M, N, K);
+        default: return launch_gemm256_inst<__bf16, MMISS_EPI_BIAS_RESID_F32>(st, A, W, ep, M, N, K);
+    }
+}

@@ -58,6 +58,38 @@ def test_tiny_text_tower_and_short_sequences(tiny):
     assert (1 - _cos(out2, ref)).max() < COS_TOL
 
 
+def test_last_layer_pruning_matches_full_computation(tiny):
+    """Without taps the last layer's out-proj / MLP run on the pooled rows only; rows do not mix after attention,
+    so the embeddings must equal the unpruned path (the `tiny` fixture records taps = unpruned)."""
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+
+    enc, W, co = tiny
+    s = co.TINY
+    pruned = ClipEncoder(ClipShape.from_any(s), max_batch_image=8, max_batch_text=8)
+    pruned.load_state_dict(W)
+    rng = np.random.Generator(np.random.Philox(77))
+    px = rng.standard_normal((7, 3, s.v_image, s.v_image), dtype=np.float32)
+    ids = co.synthetic_text_ids(7, s.t_ctx, s.t_vocab, s.eos_token_id, seed=78)
+    np.testing.assert_allclose(pruned.encode_image(px), enc.encode_image(px), atol=1e-6)
+    np.testing.assert_allclose(pruned.encode_text(ids), enc.encode_text(ids), atol=1e-6)
+    assert (1 - _cos(pruned.encode_text(ids), co.embed_texts(ids, W, s))).max() < COS_TOL
+
+
+def test_patch14_padded_k_and_odd_token_count():
+    """ViT-L/14-style geometry: patch 14 -> 3*14*14 = 588 is padded to 640 for the MFMA K loop; T = 17 tokens."""
+    import dataclasses
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.TINY, v_patch=14, v_image=56)
+    W = co.init_weights(s, seed=5)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=4, max_batch_text=4)
+    enc.load_state_dict(W)
+    rng = np.random.Generator(np.random.Philox(79))
+    px = rng.standard_normal((3, 3, 56, 56), dtype=np.float32)
+    assert (1 - _cos(enc.encode_image(px), co.embed_images(px, W, s))).max() < COS_TOL
+
+
 def test_chunking_beyond_max_batch(tiny):
     enc, W, co = tiny
     s = co.TINY

@@ -70,6 +70,37 @@ def test_gemm_tile_heights(env, bm, M):
     assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 128), (512, 256, 192), (768, 768, 768), (1280, 2304, 768), (256, 3072, 3072)])
+def test_gemm_256_tile_pipeline(env, M, N, K):
+    """The 256x256 phase-pipelined kernel: K-tile counts 1, 2, 3, 12, 48 cover prologue, tail and steady state
+    of its counted-vmcnt schedule. Repeated to catch a schedule race (RAW/WAR on the LDS slots)."""
+    torch, _lib, lib = env
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().T
+    tol = 2e-4 * max(1.0, ref.abs().max().item())
+    for rep in range(5):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _gemm(env, _lib.EPI_F32, A, W, out, bm=256)
+        assert (out - ref).abs().max().item() <= tol, rep
+    ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, ob, bias=bias, bm=256)
+    r2 = ref + bias
+    assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    x = x0.clone()
+    _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias, bm=256)
+    assert torch.allclose(x, x0 + ref + bias, rtol=1e-5, atol=2e-4)
+    # bit-identical to the 128-row kernel: same per-element k order
+    o128 = torch.zeros(M, N, device="cuda")
+    o256 = torch.zeros(M, N, device="cuda")
+    _gemm(env, _lib.EPI_F32, A, W, o128, bm=128)
+    _gemm(env, _lib.EPI_F32, A, W, o256, bm=256)
+    assert torch.equal(o128, o256)
+
+
 def test_gemm_asymmetric_layout(env):
     """A = identity-like, asymmetric W: catches a transposed or permuted C write (guide §3)."""
     torch, _lib, lib = env
