@@ -73,6 +73,87 @@ template <> struct MfmaIn<_Float16> {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Epilogue through LDS: the MFMA accumulator gives a lane 4 consecutive n of ONE row, so direct stores touch every
+// 128-byte line in 32- or 64-byte pieces from 2-4 different instructions (measured: 2.3-2.5 TB/s of output for the
+// bf16 epilogues, tools/gemm_ksweep.py: the fixed cost of a K=768 GEMM was 40 % of its time). Each wave instead
+// transposes 16 rows at a time through a private 16 x 64 LDS patch (row stride padded by 16 B) and then moves
+// whole 128-byte row segments: 8 consecutive lanes x 16 B per row, 8 rows per instruction.
+// ------------------------------------------------------------------------------------------------
+#define EPI_PATCH_BYTES (16 * 272)  // per wave: 16 rows x (64 f32 + 16 B pad); bf16 rows use 144 B of it
+
+template <int EPI, int JT>
+__device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4][JT], int m_wave, int n_wave, char* patch,
+                                              int lane) {
+    const int fr = lane & 15, fg = lane >> 4;
+    const int rrow = lane >> 3, rchunk = lane & 7;  // read-back role: row (of 8) and 16-byte chunk (of 8)
+    constexpr bool OUT_BF16 = (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16);
+    f32x4 bias[4];
+    if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + n_wave + i * 16 + 4 * fg);
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        // ---- transpose-in: lane (fr = row, fg) owns columns i*16 + 4*fg .. +3
+        if constexpr (OUT_BF16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = acc[i][j][r] + bias[i][r];
+                    if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[r] = quick_gelu(y[r]);
+                }
+                u32x2 pk;
+                pk[0] = pack_bf16x2(y[0], y[1]);
+                pk[1] = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<u32x2*>(patch + fr * 144 + i * 32 + fg * 8) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = acc[i][j];
+                if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) v += bias[i];
+                *reinterpret_cast<f32x4*>(patch + fr * 272 + i * 64 + fg * 16) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- row-major out: 8 lanes x 16 B = one 128-byte segment per row, 8 rows per instruction
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+            const int row = rh * 8 + rrow;
+            const int m = m_wave + j * 16 + row;
+            if constexpr (OUT_BF16) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 144 + rchunk * 16);
+                if (m < ep.m_valid)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_wave + rchunk * 8) = v;
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 272 + ch * 128 + rchunk * 16);
+                    const int n = n_wave + ch * 32 + rchunk * 4;
+                    if (m < ep.m_valid) {
+                        if constexpr (EPI == MMISS_EPI_F32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n) = v;
+                        } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+                            float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
+                            *reinterpret_cast<f32x4*>(p) = *reinterpret_cast<const f32x4*>(p) + v;
+                        } else if constexpr (EPI == MMISS_EPI_PATCH_F32) {
+                            const int img = m / ep.p0, pt = m - img * ep.p0;
+                            const f32x4 pos = *reinterpret_cast<const f32x4*>(ep.aux + (size_t)(1 + pt) * ep.ldo + n);
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + ((size_t)img * ep.p1 + 1 + pt) * ep.ldo + n) = v + pos;
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next j
+    }
+}
+
 template <typename IN, int BM, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M,
                                                         int N, int K, GemmEpi ep) {
@@ -177,50 +258,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
         return;
     }
 
-    f32x4 bias[4];
-    if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + n_base + i * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < JT; ++j) {
-        const int m = m_base + j * 16;
-        if (m >= ep.m_valid) continue;
-        if constexpr (EPI == MMISS_EPI_F32) {
-            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = acc[i][j];
-        } else if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16) {
-            uint16_t* row = reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_base;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float y[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    y[r] = acc[i][j][r] + bias[i][r];
-                    if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[r] = quick_gelu(y[r]);
-                }
-                u32x2 pk;
-                pk[0] = pack_bf16x2(y[0], y[1]);
-                pk[1] = pack_bf16x2(y[2], y[3]);
-                *reinterpret_cast<u32x2*>(row + i * 16) = pk;
-            }
-        } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
-            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
-            f32x4 x[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + i * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = x[i] + acc[i][j] + bias[i];
-        } else if constexpr (EPI == MMISS_EPI_PATCH_F32) {
-            const int img = m / ep.p0, patch = m - img * ep.p0;
-            const float* pos = ep.aux + (size_t)(1 + patch) * ep.ldo + n_base;
-            float* row = reinterpret_cast<float*>(ep.out) + ((size_t)img * ep.p1 + 1 + patch) * ep.ldo + n_base;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<f32x4*>(row + i * 16) = acc[i][j] + *reinterpret_cast<const f32x4*>(pos + i * 16);
-        }
-    }
+    // all waves are past the loop's last barrier: the staging buffers are dead, each wave takes a private patch
+    gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / 2), bn * GEMM_BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane);
 }
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }

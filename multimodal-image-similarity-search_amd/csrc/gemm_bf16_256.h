@@ -162,46 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ 
 #undef G256_WAIT
 #undef G256_BARRIER
 
-    // acc[i][j][reg] = C[m = m_base + j*16][n = n_base + i*16 + reg]
-    const int m_base = bm * 256 + wm * 128 + fr;
-    const int n_base = bn * 256 + wn * 64 + 4 * fg;
-    f32x4 bias[4];
-    if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + n_base + i * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int m = m_base + j * 16;
-        if (m >= ep.m_valid) continue;
-        if constexpr (EPI == MMISS_EPI_F32) {
-            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = acc[i][j];
-        } else if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16) {
-            uint16_t* row = reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_base;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float y[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    y[r] = acc[i][j][r] + bias[i][r];
-                    if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[r] = quick_gelu(y[r]);
-                }
-                u32x2 pk;
-                pk[0] = pack_bf16x2(y[0], y[1]);
-                pk[1] = pack_bf16x2(y[2], y[3]);
-                *reinterpret_cast<u32x2*>(row + i * 16) = pk;
-            }
-        } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
-            float* row = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n_base;
-            f32x4 x[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + i * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(row + i * 16) = x[i] + acc[i][j] + bias[i];
-        }
-    }
+    gemm_epilogue<EPI, 8>(ep, acc, bm * 256 + wm * 128, bn * 256 + wn * 64, smem + wave * EPI_PATCH_BYTES, lane);
 }
 
 template <typename IN, int EPI>
