@@ -88,6 +88,7 @@ SIGNATURES = {
     "mmiss_dbg_attention": (_I, [_I, _P, _P, _P, _I32, _I32, _I32, _I32]),
     "mmiss_dbg_im2col": (_I, [_I, _P, _P, _P, _I32, _I32, _I32, _I32]),
     "mmiss_dbg_encoder_record_taps": (_I, [_P, _I]),
+    "mmiss_dbg_encoder_set_fuse_ln": (_I, [_P, _I]),
 }
 
 _lib = None

@@ -47,6 +47,7 @@ struct Tower {
     int ws_batch = 0;
     DevBuf x, h, qkv, ctx, u, pooled, proj_out, pool_row, out_stage, taps;
     DevBuf xc, hc, ctxc, uc;  // compact [Bp, *] buffers of the pooled rows (last-layer pruning)
+    DevBuf stats;             // [Mp][hidden/64][2] partial row (sum, sumsq) for the LayerNorm-fused GEMMs
     bool pooled_compact = false;
     int last_B = 0, last_T = 0;
     int64_t tap_stride = 0;  // floats per recorded tap
@@ -72,6 +73,10 @@ struct mmiss_encoder {
     std::mutex mu;
     bool finalized = false;
     bool record_taps = false;
+    // LayerNorm folded into the QKV / FC1 GEMM A-operand staging. Correct, but measured SLOWER at B=256 (every one of
+    // the 18-24 column blocks re-normalises its f32 rows through registers: 342-371 TF vs 768-843 TF + a 14 us
+    // LayerNorm pass), so it is off by default and kept as an option for small batches / later rework.
+    bool fuse_ln = false;
 
     Tower vis, txt;
     // vision-only
@@ -167,6 +172,7 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     MM_TRY(alloc_zero(tw.hc, (size_t)Bp * d * 2));
     MM_TRY(alloc_zero(tw.ctxc, (size_t)Bp * d * 2));
     MM_TRY(alloc_zero(tw.uc, (size_t)Bp * tw.mlp * 2));
+    MM_TRY(alloc_zero(tw.stats, (size_t)Mp * (d / 64) * 2 * 4));
     if (e->record_taps) {
         tw.tap_stride = Mp * d;
         MM_TRY(alloc_zero(tw.taps, (size_t)(tw.layers + 1) * tw.tap_stride * 4));
@@ -194,13 +200,27 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // rows only (compacted). Kept off while taps are recorded so the tests can compare every row of every layer.
     const bool prune = !e->record_taps;
     tw.pooled_compact = false;
+    const bool fuse = e->fuse_ln;
+    const int parts = d / 64;
+    if (fuse) {
+        MM_PROF("row_stats", st, 3.0 * M * d, 4.0 * M * d);
+        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(), M,
+                           d, parts);
+        MM_HIP(hipGetLastError());
+    }
     for (int l = 0; l < tw.layers; ++l) {
         LayerW& L = tw.L[l];
-        MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
-                                d, eps));
         GemmEpi ep{};
         ep.out = tw.qkv.p; ep.bias = L.bqkv.as<float>(); ep.ldo = 3 * d; ep.m_valid = M;
-        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
+        if (fuse) {
+            ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln1g.as<float>(); ep.ln_b = L.ln1b.as<float>();
+            ep.ln_parts = parts; ep.ln_eps = eps;
+            MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.x.as<float>(), L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
+        } else {
+            MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
+                                    d, eps));
+            MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
+        }
         MM_TRY(launch_attention(st, tw.qkv.p, tw.ctx.p, B, tw.T, tw.heads, causal));
         if (prune && l == tw.layers - 1) {
             const int Bp = (int)round_up(B, 128);
@@ -226,14 +246,22 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = M;
+        ep.stats_out = fuse ? tw.stats.as<float>() : nullptr;  // row statistics of the new residual for LN2
         MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
-        MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
-                                d, eps));
         ep = GemmEpi{};
         ep.out = tw.u.p; ep.bias = L.b1.as<float>(); ep.ldo = tw.mlp; ep.m_valid = M;
-        MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.h.p, L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
+        if (fuse) {
+            ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln2g.as<float>(); ep.ln_b = L.ln2b.as<float>();
+            ep.ln_parts = parts; ep.ln_eps = eps;
+            MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.x.as<float>(), L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
+        } else {
+            MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
+                                    d, eps));
+            MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.h.p, L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
+        }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = M;
+        ep.stats_out = fuse ? tw.stats.as<float>() : nullptr;  // ... and for the next layer's LN1
         MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         MM_TRY(tap(l + 1));
     }
@@ -533,6 +561,13 @@ extern "C" int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t
         }
     }
     return finish_call(enc, st, !out_dev);
+}
+
+extern "C" int mmiss_dbg_encoder_set_fuse_ln(mmiss_encoder* enc, int on) {
+    if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
+    std::lock_guard<std::mutex> lk(enc->mu);
+    enc->fuse_ln = on != 0;
+    return MMISS_OK;
 }
 
 extern "C" int mmiss_dbg_encoder_record_taps(mmiss_encoder* enc, int on) {

@@ -178,6 +178,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Row statistics for the LayerNorm-fused GEMM (gemm_bf16.h, ALN): stats[r][0] = (sum, sumsq) of row r, the other
+// parts zero. Only needed once per forward (the embeddings); afterwards the residual GEMM epilogues produce them.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int M,
+                                                        int d, int parts) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const float* xr = x + (size_t)r * d;
+    float s = 0.f, q = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+        q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    float* o = stats + (size_t)r * parts * 2;
+    for (int i = lane; i < parts * 2; i += 64) o[i] = (i == 0) ? s : (i == 1 ? q : 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: multi-head attention core, head_dim 64:  ctx = softmax(Q K^T * 64^-0.5 (+causal mask)) V
 // (HF:modeling_clip.py:259-277,280-335; text mask :543-548). Softmax statistics in fp32 as HF does.

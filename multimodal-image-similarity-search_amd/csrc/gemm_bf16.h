@@ -27,6 +27,14 @@ struct GemmEpi {
     int m_valid;        // rows >= m_valid are not stored
     int p0, p1;         // PATCH: p0 = patches per image (G), p1 = tokens per image (T). GROUPMAX: p0 = valid n
     int m_fast;         // block order: 0 = n fastest (blocks sharing an A panel adjacent), 1 = m fastest
+    // LayerNorm fused into the A operand (ALN kernels: A is the f32 residual stream, normalised while it is staged)
+    const float* ln_stats;  // [M][ln_parts][2] partial (sum, sum of squares) of every row
+    const float* ln_g;      // gamma [K]
+    const float* ln_b;      // beta  [K]
+    int ln_parts;
+    float ln_eps;
+    // BIAS_RESID_F32: if set, partial (sum, sumsq) of the NEW residual rows, [M][N/64][2] — the next LayerNorm's input
+    float* stats_out;
 };
 
 #define MMISS_EPI_GROUPMAX_F32 5  // internal: out f32 [M, N/16] = max over the lane's 16 n (see decode below)
@@ -131,6 +139,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
                 if (m < ep.m_valid)
                     *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_wave + rchunk * 8) = v;
             } else {
+                float rs = 0.f, rq = 0.f;  // this lane's share of the row's (sum, sumsq) over the wave's 64 columns
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 272 + ch * 128 + rchunk * 16);
@@ -140,11 +149,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
                             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n) = v;
                         } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
                             float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
-                            *reinterpret_cast<f32x4*>(p) = *reinterpret_cast<const f32x4*>(p) + v;
+                            v = *reinterpret_cast<const f32x4*>(p) + v;
+                            *reinterpret_cast<f32x4*>(p) = v;
+                            rs += (v[0] + v[1]) + (v[2] + v[3]);
+                            rq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         } else if constexpr (EPI == MMISS_EPI_PATCH_F32) {
                             const int img = m / ep.p0, pt = m - img * ep.p0;
                             const f32x4 pos = *reinterpret_cast<const f32x4*>(ep.aux + (size_t)(1 + pt) * ep.ldo + n);
                             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + ((size_t)img * ep.p1 + 1 + pt) * ep.ldo + n) = v + pos;
+                        }
+                    }
+                }
+                if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+                    if (ep.stats_out) {  // 8 lanes hold one row: fixed-order xor tree, one writer -> deterministic
+                        rs += __shfl_xor(rs, 1); rq += __shfl_xor(rq, 1);
+                        rs += __shfl_xor(rs, 2); rq += __shfl_xor(rq, 2);
+                        rs += __shfl_xor(rs, 4); rq += __shfl_xor(rq, 4);
+                        if (rchunk == 0 && m < ep.m_valid) {
+                            float* so = ep.stats_out + ((size_t)m * (ep.ldo >> 6) + (n_wave >> 6)) * 2;
+                            so[0] = rs;
+                            so[1] = rq;
                         }
                     }
                 }
@@ -154,13 +178,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
     }
 }
 
-template <typename IN, int BM, int EPI>
+// ALN = true: `A` is really the f32 residual stream x [M,K]; the A tile is LayerNorm(x) (HF:modeling_clip.py:358-360,
+// fp32 statistics from ep.ln_stats, affine ep.ln_g / ep.ln_b), computed and rounded to bf16 while it is staged
+// through registers into the same swizzled LDS image. This removes the separate LayerNorm pass (59 MB per call at
+// B=256) and its kernel boundary; the W tile keeps its LDS-DMA path.
+template <typename IN, int BM, int EPI, bool ALN = false>
 __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M,
                                                         int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename MfmaIn<IN>::frag frag;
     constexpr int JT = BM / 32;               // 16-row m sub-tiles per wave (wave tile = BM/2 x 64)
     constexpr int A_BYTES = BM * 128, W_BYTES = GEMM_BN * 128, BUF = A_BYTES + W_BYTES;
+    constexpr int RPT = BM / 32;              // ALN: rows per thread (thread t: 16-byte chunk t&7 of rows (t>>3) + 32 i)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -182,10 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
         char* sA = smem + buf * BUF;
         char* sW = sA + A_BYTES;
         const size_t koff = (size_t)kt * GEMM_BK + src_chunk;
+        if constexpr (!ALN) {
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {
-            const int rowblk = wave * (BM / 32) + i;
-            glds16(Ab + (size_t)(rowblk * 8 + r_in) * K + koff, sA + rowblk * 1024);
+            for (int i = 0; i < BM / 32; ++i) {
+                const int rowblk = wave * (BM / 32) + i;
+                glds16(Ab + (size_t)(rowblk * 8 + r_in) * K + koff, sA + rowblk * 1024);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -203,13 +234,70 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
         for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = K / GEMM_BK;
+
+    // ---- ALN: per-row (mean, rstd) from the partial sums, register staging of the f32 tile
+    const int xc8 = tid & 7, xr0 = tid >> 3;
+    float ln_mean[RPT], ln_rstd[RPT];
+    f32x4 xr[RPT][2];
+    const float* Xb = reinterpret_cast<const float*>(A) + (size_t)bm * BM * K;
+    auto x_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const float* src = Xb + (size_t)(xr0 + 32 * i) * K + kt * GEMM_BK + xc8 * 8;
+            xr[i][0] = *reinterpret_cast<const f32x4*>(src);
+            xr[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+    };
+    auto x_write = [&](int buf, int kt) {
+        char* sA = smem + buf * BUF;
+        const int k0 = kt * GEMM_BK + xc8 * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ep.ln_g + k0), g1 = *reinterpret_cast<const f32x4*>(ep.ln_g + k0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ep.ln_b + k0), b1 = *reinterpret_cast<const f32x4*>(ep.ln_b + k0 + 4);
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int row = xr0 + 32 * i;
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (xr[i][0][e] - ln_mean[i]) * ln_rstd[i] * g0[e] + b0[e];
+                y[4 + e] = (xr[i][1][e] - ln_mean[i]) * ln_rstd[i] * g1[e] + b1[e];
+            }
+            u32x4 pk;
+            pk[0] = pack_bf16x2(y[0], y[1]); pk[1] = pack_bf16x2(y[2], y[3]);
+            pk[2] = pack_bf16x2(y[4], y[5]); pk[3] = pack_bf16x2(y[6], y[7]);
+            *reinterpret_cast<u32x4*>(sA + row * 128 + ((xc8 ^ (row & 7)) << 4)) = pk;
+        }
+    };
+    if constexpr (ALN) {
+        float* srow = reinterpret_cast<float*>(smem + 2 * BUF);  // [BM][2] behind the staging buffers
+        if (tid < BM) {
+            const float* st = ep.ln_stats + (size_t)(bm * BM + tid) * ep.ln_parts * 2;
+            float s1 = 0.f, s2 = 0.f;
+            for (int pp = 0; pp < ep.ln_parts; ++pp) { s1 += st[2 * pp]; s2 += st[2 * pp + 1]; }
+            const float mean = s1 / (float)K;
+            const float var = fmaxf(s2 / (float)K - mean * mean, 0.f);
+            srow[2 * tid] = mean;
+            srow[2 * tid + 1] = 1.0f / sqrtf(var + ep.ln_eps);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            ln_mean[i] = srow[2 * (xr0 + 32 * i)];
+            ln_rstd[i] = srow[2 * (xr0 + 32 * i) + 1];
+        }
+        x_load(0);
+    }
     stage(0, 0);
+    if constexpr (ALN) x_write(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) stage(cur ^ 1, t + 1);
+        if (t + 1 < nt) {
+            stage(cur ^ 1, t + 1);
+            if constexpr (ALN) x_load(t + 1);  // f32 rows of the next K-tile fly during this tile's MFMAs
+        }
         const char* sA = smem + cur * BUF;
         const char* sW = sA + A_BYTES;
 #pragma unroll
@@ -230,6 +318,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < JT; ++j) acc[i][j] = MfmaIn<IN>::mma(wf[i], af[j], acc[i][j]);
+        }
+        if constexpr (ALN) {
+            if (t + 1 < nt) x_write(cur ^ 1, t + 1);  // buffer cur^1 was last read before the previous barrier
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -283,20 +374,44 @@ static inline int gemm_pick_bm(int64_t M_rows, int N) {
     return best;
 }
 
-template <typename IN, int BM, int EPI>
+template <typename IN, int BM, int EPI, bool ALN = false>
 static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
-    constexpr int LDS = 2 * (BM + GEMM_BN) * 128;
+    constexpr int LDS = 2 * (BM + GEMM_BN) * 128 + (ALN ? BM * 8 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI>),
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
     }
     const int nwg = (M / BM) * (N / GEMM_BN);
-    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI>), dim3(nwg), dim3(256), LDS, st, reinterpret_cast<const IN*>(A),
+    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN>), dim3(nwg), dim3(256), LDS, st, reinterpret_cast<const IN*>(A),
                        reinterpret_cast<const IN*>(W), M, N, K, ep);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
+}
+
+// LayerNorm-fused bf16 GEMM: X f32 [M,K] (the residual stream), ep.ln_* set; epilogues BIAS_BF16 / BIAS_QGELU_BF16.
+static int launch_gemm_ln(hipStream_t st, int epi, int bm, const float* X, const void* W, const GemmEpi& ep, int M, int N,
+                          int K) {
+    if (bm == 0) bm = 128;
+    if (M <= 0 || N <= 0 || K <= 0 || (M % bm) || (N % GEMM_BN) || (K % GEMM_BK) || !ep.ln_stats || !ep.ln_g || !ep.ln_b)
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm_ln: M=%d N=%d K=%d bm=%d", M, N, K, bm);
+    const int mv = ep.m_valid < M ? ep.m_valid : M;
+    const double bytes = 4.0 * (double)mv * K + 2.0 * (double)N * K + 2.0 * (double)mv * N;
+    MM_PROF(epi == MMISS_EPI_BIAS_BF16 ? "gemm_ln_bf16_bias" : "gemm_ln_bf16_bias_qgelu", st, 2.0 * mv * N * K, bytes);
+#define GEMM_LN_CASE(BMV)                                                                                          \
+    case BMV:                                                                                                      \
+        return epi == MMISS_EPI_BIAS_BF16                                                                          \
+                   ? launch_gemm_inst<__bf16, BMV, MMISS_EPI_BIAS_BF16, true>(st, X, W, ep, M, N, K)               \
+                   : launch_gemm_inst<__bf16, BMV, MMISS_EPI_BIAS_QGELU_BF16, true>(st, X, W, ep, M, N, K);
+    if (epi != MMISS_EPI_BIAS_BF16 && epi != MMISS_EPI_BIAS_QGELU_BF16) MM_FAIL(MMISS_ERR_ARG, "gemm_ln: epilogue %d", epi);
+    switch (bm) {
+        GEMM_LN_CASE(128)
+        GEMM_LN_CASE(160)
+        GEMM_LN_CASE(192)
+    }
+#undef GEMM_LN_CASE
+    MM_FAIL(MMISS_ERR_ARG, "gemm_ln: unsupported tile height %d", bm);
 }
 
 template <typename IN, int EPI>

@@ -217,6 +217,9 @@ class ClipEncoder:
     def record_taps(self, on: bool = True):
         _lib.check(self._lib.mmiss_dbg_encoder_record_taps(self._h, 1 if on else 0))
 
+    def set_fuse_ln(self, on: bool = True):
+        _lib.check(self._lib.mmiss_dbg_encoder_set_fuse_ln(self._h, 1 if on else 0))
+
     def tap(self, tower: int, what: int, n: int) -> np.ndarray:
         out = np.empty(n, dtype=np.float32)
         w = C.c_int64(0)

@@ -75,6 +75,28 @@ def test_last_layer_pruning_matches_full_computation(tiny):
     assert (1 - _cos(pruned.encode_text(ids), co.embed_texts(ids, W, s))).max() < COS_TOL
 
 
+def test_layernorm_fused_gemm_matches_separate_layernorm(tiny):
+    """LayerNorm folded into the QKV / FC1 operand staging (row statistics produced by the residual GEMM
+    epilogues) against the separate LayerNorm kernels: same embeddings to rounding."""
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+
+    enc, W, co = tiny
+    s = co.TINY
+    fused = ClipEncoder(ClipShape.from_any(s), max_batch_image=8, max_batch_text=8)
+    fused.load_state_dict(W)
+    fused.set_fuse_ln(True)
+    plain = enc
+    enc = fused
+    rng = np.random.Generator(np.random.Philox(91))
+    px = rng.standard_normal((6, 3, s.v_image, s.v_image), dtype=np.float32) * 3 + 1.5  # non-zero row means
+    ids = co.synthetic_text_ids(6, s.t_ctx, s.t_vocab, s.eos_token_id, seed=92)
+    a, b = enc.encode_image(px), plain.encode_image(px)
+    assert (1 - _cos(a, b)).max() < 2e-5
+    assert (1 - _cos(a, co.embed_images(px, W, s))).max() < COS_TOL
+    assert (1 - _cos(b, co.embed_images(px, W, s))).max() < COS_TOL
+    assert (1 - _cos(enc.encode_text(ids), plain.encode_text(ids))).max() < 2e-5
+
+
 def test_patch14_padded_k_and_odd_token_count():
     """ViT-L/14-style geometry: patch 14 -> 3*14*14 = 588 is padded to 640 for the MFMA K loop; T = 17 tokens."""
     import dataclasses
