@@ -263,7 +263,13 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
             dt = float(t.item())
         scan = prof.get("scan_topk_f16")
         entry = {"ms_per_batch": round(dt * 1e3, 3), "mvec_per_s": round(N / dt / 1e6, 1),
-                 "gpairs_per_s": round(Q * N / dt / 1e9, 2)}
+                 "gpairs_per_s": round(Q * N / dt / 1e9, 2),
+                 "kernel_ms": {k: round(p["ms"] / iters, 4) for k, p in prof.items()}}
+        sg = prof.get("score_gemm_f16")
+        if sg:
+            sg_ms = sg["ms"] / sg["launches"]
+            tfl = 2.0 * Q * per * D / sg_ms / 1e9
+            entry["score_gemm"] = {"avg_ms": round(sg_ms, 4), "tflops": round(tfl, 1), "mfma_frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4)}
         if scan:
             scan_ms = scan["ms"] / scan["launches"]
             gbs = per * D * 2 / scan_ms / 1e6

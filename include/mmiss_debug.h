@@ -50,6 +50,9 @@ int mmiss_dbg_encoder_record_taps(struct mmiss_encoder* enc, int on);
 /* 1 (default): LayerNorm is folded into the QKV / FC1 GEMMs; 0: separate LayerNorm kernels (A/B and parity tests) */
 int mmiss_dbg_encoder_set_fuse_ln(struct mmiss_encoder* enc, int on);
 
+/* process-wide integer tuning knob (A/B experiments from tools/): e.g. "scan_group" = 8 | 16 */
+int mmiss_dbg_set_option(const char* key, int value);
+
 #ifdef __cplusplus
 }
 #endif

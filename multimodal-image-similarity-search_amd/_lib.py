@@ -89,6 +89,7 @@ SIGNATURES = {
     "mmiss_dbg_im2col": (_I, [_I, _P, _P, _P, _I32, _I32, _I32, _I32]),
     "mmiss_dbg_encoder_record_taps": (_I, [_P, _I]),
     "mmiss_dbg_encoder_set_fuse_ln": (_I, [_P, _I]),
+    "mmiss_dbg_set_option": (_I, [C.c_char_p, _I]),
 }
 
 _lib = None
@@ -152,6 +153,10 @@ def current_stream_ptr(device=None):
     import torch
 
     return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def set_option(key: str, value: int) -> None:
+    check(load().mmiss_dbg_set_option(key.encode(), int(value)))
 
 
 def prof_enable(on: bool) -> None:

@@ -2,6 +2,7 @@
 // stateless glue kernels (blend, shard merge).
 #include "common.h"
 #include "retrieval_kernels.h"
+#include "gemm_bf16_256.h"
 #include <algorithm>
 
 struct mmiss_index {
@@ -13,7 +14,7 @@ struct mmiss_index {
     DevBuf rows, labels_d;
     std::vector<int64_t> labels_h;
     // scratch
-    DevBuf stage, qn, qs, qstage, lists_s, lists_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, gmax;
+    DevBuf stage, qn, qs, qstage, lists_s, lists_r, lists2_s, lists2_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, gmax;
     hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
 };
 
@@ -66,15 +67,15 @@ int64_t find_row(const mmiss_index* ix, int64_t label) {
     return it - ix->labels_h.begin();
 }
 
-template <typename T, int NQT, int CAP>
+template <typename T, int NQT, int CAP, int GS = 8>
 int launch_scan_t(hipStream_t st, const ScanArgs& a, int slabs, int qtiles, int lds) {
     static int attr_lds = 0;
     if (lds > attr_lds) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_kernel<T, NQT, CAP>),
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_kernel<T, NQT, CAP, GS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((scan_topk_kernel<T, NQT, CAP>), dim3(slabs, qtiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((scan_topk_kernel<T, NQT, CAP, GS>), dim3(slabs, qtiles), dim3(256), lds, st, a);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }
@@ -99,9 +100,9 @@ ScanPlan plan_scan(int D, int elt, int Q, int kp, int64_t N) {
     p.qtiles = (Q + NQ - 1) / NQ;
     const int64_t ntiles = (N + 15) / 16;
     const int blocks_per_cu = std::max(1, std::min(8, limit / p.lds));
-    int64_t target = (int64_t)256 * blocks_per_cu * 2 / p.qtiles;
+    int64_t target = (int64_t)256 * blocks_per_cu * mmiss_option("scan_rounds", 1) / p.qtiles;
     if (target < 1) target = 1;
-    if (target > 1024) target = 1024;
+    if (target > mmiss_option("scan_max_slabs", 1024)) target = mmiss_option("scan_max_slabs", 1024);
     int64_t tpb = (ntiles + target - 1) / target;
     tpb = (tpb + 3) / 4 * 4;  // every wave of a block gets the same number of tiles
     if (tpb < 4) tpb = 4;
@@ -115,13 +116,41 @@ int launch_scan(mmiss_index* ix, hipStream_t st, const ScanArgs& a, const ScanPl
     const double bytes = (double)a.N * a.D * ix->elt;
     MM_PROF(ix->dtype == MMISS_F16 ? "scan_topk_f16" : "scan_topk_f32", st, flops, bytes);
     if (ix->dtype == MMISS_F16) {
-        if (p.nqt == 1) return launch_scan_t<_Float16, 1, 64>(st, a, p.slabs, p.qtiles, p.lds);
+        if (p.nqt == 1) {
+            if (mmiss_option("scan_group", 8) == 16) return launch_scan_t<_Float16, 1, 64, 16>(st, a, p.slabs, p.qtiles, p.lds);
+            return launch_scan_t<_Float16, 1, 64>(st, a, p.slabs, p.qtiles, p.lds);
+        }
         if (p.nqt == 2) return launch_scan_t<_Float16, 2, 32>(st, a, p.slabs, p.qtiles, p.lds);
         return launch_scan_t<_Float16, 4, 32>(st, a, p.slabs, p.qtiles, p.lds);
     }
     if (p.nqt == 1) return launch_scan_t<float, 1, 64>(st, a, p.slabs, p.qtiles, p.lds);
     if (p.nqt == 2) return launch_scan_t<float, 2, 32>(st, a, p.slabs, p.qtiles, p.lds);
     return launch_scan_t<float, 4, 32>(st, a, p.slabs, p.qtiles, p.lds);
+}
+
+// merge L per-slab lists of every query into its candidate page; above 64 lists in two levels so that a single
+// query (the API path) is not merged by one lone workgroup
+int launch_merge(mmiss_index* ix, hipStream_t st, MergeArgs m) {
+    if (m.L > 64) {
+        const int per = 32;
+        const int S = (m.L + per - 1) / per;
+        MM_TRY(ix->lists2_s.ensure((size_t)S * m.Q * m.kp * 4));
+        MM_TRY(ix->lists2_r.ensure((size_t)S * m.Q * m.kp * 4));
+        MergeArgs m1 = m;
+        m1.lists_per_block = per; m1.out_s = ix->lists2_s.as<float>(); m1.out_r = ix->lists2_r.as<int32_t>();
+        m1.cur_s = nullptr; m1.cur_r = nullptr;
+        {
+            MM_PROF("merge_lists", st, 0.0, (double)m.L * m.Q * m.kp * 8);
+            hipLaunchKernelGGL(merge_lists_kernel, dim3(m.Q, S), dim3(256), 0, st, m1);
+            MM_HIP(hipGetLastError());
+        }
+        m.in_s = ix->lists2_s.as<float>(); m.in_r = ix->lists2_r.as<int32_t>(); m.L = S;
+    }
+    m.lists_per_block = 0; m.out_s = nullptr; m.out_r = nullptr;
+    MM_PROF("merge_lists", st, 0.0, (double)m.L * m.Q * m.kp * 8);
+    hipLaunchKernelGGL(merge_lists_kernel, dim3(m.Q), dim3(256), 0, st, m);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
 }
 
 }  // namespace
@@ -377,7 +406,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     if (ncand > 2048) MM_FAIL(MMISS_ERR_UNSUPPORTED, "mmiss_index_query: k = %d too large (max 2040)", k);
 
     // queries -> device, canonical normalisation
-    const int Qpad = (int)round_up(Q, 128);
+    const int Qpad = (int)round_up(Q, 256);
     const float* qsrc = queries;
     if (!mmiss_is_device_ptr(queries)) {
         MM_TRY(ix->qstage.ensure((size_t)Q * D * 4));
@@ -404,16 +433,22 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     if (N == 0) {
         MM_HIP(hipMemsetAsync(ix->cand.p, 0xff, (size_t)Q * ncand * 4, st));  // all -1
     } else if (dense) {
-        const int64_t Npad = round_up(N, 128);  // capacity is a multiple of 128: the pad rows are readable, and masked
+        // the pad rows up to the tile multiple are readable (capacity is a multiple of 1024) and masked in the epilogue
+        const bool big = Q > 128;  // 256x256 phase-pipelined tile once there are two 128-query tiles to share a row panel
+        const int64_t Npad = round_up(N, big ? 256 : 128);
+        const int Mq = (int)round_up(Q, big ? 256 : 128);
         const int ng = (int)(Npad / 16);
-        MM_TRY(ix->gmax.ensure((size_t)Qpad * ng * 4));
+        MM_TRY(ix->gmax.ensure((size_t)Mq * ng * 4));
         GemmEpi ep{};
         ep.out = ix->gmax.p; ep.ldo = ng; ep.m_valid = Q; ep.p0 = (int)N; ep.m_fast = 1;
         {
             MM_PROF("score_gemm_f16", st, 2.0 * Q * (double)N * D, (double)N * D * 2);
-            MM_TRY((launch_gemm_inst<_Float16, 128, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Qpad, (int)Npad, D)));
+            if (big)
+                MM_TRY((launch_gemm256_inst<_Float16, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D)));
+            else
+                MM_TRY((launch_gemm_inst<_Float16, 128, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D)));
         }
-        const int units = (ng + 255) / 256;
+        const int units = (ng + 1023) / 1024;
         int splits = (1024 + Q - 1) / Q;
         if (splits > units) splits = units;
         if (splits > 32) splits = 32;
@@ -432,11 +467,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
         m.L = splits; m.Q = Q; m.kp = kp;
         m.cand = ix->cand.as<int32_t>(); m.cand_stride = ncand; m.page_off = 0;
-        {
-            MM_PROF("merge_lists", st, 0.0, (double)splits * Q * kp * 8);
-            hipLaunchKernelGGL(merge_lists_kernel, dim3(Q), dim3(256), 0, st, m);
-            MM_HIP(hipGetLastError());
-        }
+        MM_TRY(launch_merge(ix, st, m));
     } else {
         const ScanPlan p = plan_scan(D, ix->elt, Q, kp, N);
         MM_TRY(ix->lists_s.ensure((size_t)p.slabs * Q * kp * 4));
@@ -465,11 +496,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
             m.cand = ix->cand.as<int32_t>(); m.cand_stride = ncand; m.page_off = page * kp;
             m.cur_s = paging ? ix->cur_s.as<float>() : nullptr;
             m.cur_r = paging ? ix->cur_r.as<int32_t>() : nullptr;
-            {
-                MM_PROF("merge_lists", st, 0.0, (double)p.slabs * Q * kp * 8);
-                hipLaunchKernelGGL(merge_lists_kernel, dim3(Q), dim3(256), 0, st, m);
-                MM_HIP(hipGetLastError());
-            }
+            MM_TRY(launch_merge(ix, st, m));
         }
     }
     {
@@ -482,7 +509,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         while (npow < r.ncand) npow <<= 1;
         const int lds = npow * 12 + 16;
         MM_PROF("rerank", st, 2.0 * Q * r.ncand * D, (double)Q * r.ncand * D * ix->elt);
-        const int threads = r.ncand >= 256 ? 1024 : 256;  // one wave per candidate row: more waves hide the gather latency
+        const int threads = r.ncand >= 16 ? 1024 : 256;  // one wave per candidate row: more waves hide the gather latency
         if (ix->dtype == MMISS_F16)
             hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(Q), dim3(threads), lds, st, r);
         else

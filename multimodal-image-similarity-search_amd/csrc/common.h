@@ -53,6 +53,9 @@ void mmiss_set_error(const char* fmt, ...);
 // is `p` device memory? (host pageable pointers make hipPointerGetAttributes fail -> host)
 bool mmiss_is_device_ptr(const void* p);
 
+// process-wide tuning knobs set through mmiss_dbg_set_option (tests / A-B experiments)
+int mmiss_option(const char* key, int dflt);
+
 // Make sure `device` is a usable gfx950 and current. Fails loudly otherwise (no CPU fallback).
 int mmiss_use_device(int device);
 

@@ -162,7 +162,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ 
 #undef G256_WAIT
 #undef G256_BARRIER
 
-    gemm_epilogue<EPI, 8>(ep, acc, bm * 256 + wm * 128, bn * 256 + wn * 64, smem + wave * EPI_PATCH_BYTES, lane);
+    if constexpr (EPI == MMISS_EPI_GROUPMAX_F32) {
+        // same group numbering as the 128-row kernel: g = (64-column block index) * 4 + fg (groupmax_row decodes it)
+        const int g = (bn * 4 + wn) * 4 + fg;
+        const int n0 = bn * 256 + wn * 64 + 4 * fg;
+        float* out = reinterpret_cast<float*>(ep.out);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (n0 + i * 16 + r < ep.p0) ? acc[i][j][r] : -INFINITY;
+                    mx = fmaxf(mx, v);
+                }
+            const int m = bm * 256 + wm * 128 + j * 16 + fr;
+            if (m < ep.m_valid) out[(size_t)m * ep.ldo + g] = mx;
+        }
+        return;
+    } else {
+        gemm_epilogue<EPI, 8>(ep, acc, bm * 256 + wm * 128, bn * 256 + wn * 64, smem + wave * EPI_PATCH_BYTES, lane);
+    }
 }
 
 template <typename IN, int EPI>

@@ -162,7 +162,7 @@ struct ScanLds {
     static __host__ __device__ int round_up16(int x) { return (x + 15) & ~15; }
 };
 
-template <typename T, int NQT, int CAP>
+template <typename T, int NQT, int CAP, int GS = 8>
 __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ELT = ScanTraits<T>::ELT;
@@ -261,6 +261,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
         };
         const int row_bytes = D * ELT;  // a multiple of 256 (checked on the host)
         int byte0 = 0;
+        if constexpr (GS == 16)
+            for (; byte0 + 1024 <= row_bytes; byte0 += 1024) steps(std::integral_constant<int, 16>{}, byte0);
         for (; byte0 + 512 <= row_bytes; byte0 += 512) steps(std::integral_constant<int, 8>{}, byte0);
         if (byte0 < row_bytes) steps(std::integral_constant<int, 4>{}, byte0);
         // filter + append
@@ -355,30 +357,44 @@ __global__ __launch_bounds__(256) void select_topk_kernel(SelectArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = blockIdx.x;
     const int nsplit = gridDim.y;
-    // this block's column range, in units of 256 columns
-    const int units = (a.ng + 255) / 256;
+    // this block's column range, in units of 1024 columns
+    const int units = (a.ng + 1023) / 1024;
     const int upb = (units + nsplit - 1) / nsplit;
-    const int c_begin = blockIdx.y * upb * 256;
-    int c_end = c_begin + upb * 256;
+    const int c_begin = blockIdx.y * upb * 1024;
+    int c_end = c_begin + upb * 1024;
     if (c_end > a.ng) c_end = a.ng;
     const float* row = a.G + (size_t)q * a.ldg;
 
     float ls = SCAN_NEG_INF;
     int lr = SCAN_ROW_NONE;
-    float tau = SCAN_NEG_INF;
-    // wave w takes columns c_begin + 64*w + lane, stepping 256
-    for (int c0 = c_begin + wave * 64; c0 < c_end; c0 += 256) {
-        const int c = c0 + lane;
-        float s = SCAN_NEG_INF;
-        if (c < c_end) s = row[c];
-        unsigned long long m = __ballot(s > tau);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const float xs = __shfl(s, src);
-            if (!(xs > tau)) continue;
-            lane_list_insert(ls, lr, xs, c0 + src, lane);
-            tau = __shfl(ls, a.kp - 1);
+    float tau = SCAN_NEG_INF;   // (tau, tau_r) = the list's kp-th entry: only values that sort before it are inserted
+    int tau_r = SCAN_ROW_NONE;
+    // wave w takes columns c_begin + 256*w + 4*lane .. +3 (one 16-byte load per lane, 1 KiB per wave), stepping 1024;
+    // c_begin and ldg are multiples of 4, so the loads are aligned
+    for (int c0 = c_begin + wave * 256; c0 < c_end; c0 += 1024) {
+        const int c = c0 + lane * 4;
+        f32x4 v = {SCAN_NEG_INF, SCAN_NEG_INF, SCAN_NEG_INF, SCAN_NEG_INF};
+        if (c + 3 < c_end) {
+            v = *reinterpret_cast<const f32x4*>(row + c);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < c_end) v[e] = row[c + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = v[e];
+            unsigned long long m = __ballot(s > tau || (s == tau && c + e < tau_r));
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float xs = __shfl(s, src);
+                const int xr = c0 + src * 4 + e;
+                if (!(xs > tau || (xs == tau && xr < tau_r))) continue;
+                lane_list_insert(ls, lr, xs, xr, lane);
+                tau = __shfl(ls, a.kp - 1);
+                tau_r = __shfl(lr, a.kp - 1);
+            }
         }
     }
     if (lane < 32) { ms[wave][lane] = ls; mr[wave][lane] = lr; }
@@ -412,6 +428,11 @@ struct MergeArgs {
     int cand_stride, page_off;
     float* cur_s;         // [Q] cursor, updated to the page's last entry (or -inf when exhausted); may be null
     int32_t* cur_r;
+    // first pass of a two-level merge (grid.y > 1): block (q, y) merges lists [y*lists_per_block, ...) and writes a
+    // LIST [gridDim.y][Q][kp] (scores kept) instead of the final candidates
+    int lists_per_block;
+    float* out_s;
+    int32_t* out_r;
 };
 
 // A wave streams 32 entries per step, so a list of <= kp (<= 32) entries can never outgrow its 64-slot
@@ -426,14 +447,17 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
     if (lane == 0) cnt[wave] = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     float tau = SCAN_NEG_INF;
-    const int64_t total = (int64_t)a.L * kp;
+    const int l_begin = a.out_s ? blockIdx.y * a.lists_per_block : 0;
+    int l_end = a.out_s ? l_begin + a.lists_per_block : a.L;
+    if (l_end > a.L) l_end = a.L;
+    const int64_t total = (int64_t)(l_end > l_begin ? l_end - l_begin : 0) * kp;
     for (int64_t e0 = (int64_t)wave * 32; e0 < total; e0 += 128) {
         const int64_t e = e0 + (lane & 31);
         float s = SCAN_NEG_INF;
         int r = -1;
         if (lane < 32 && e < total) {
-            const int64_t l = e / kp;
-            const int slot = (int)(e - l * kp);
+            const int64_t l = l_begin + e / kp;
+            const int slot = (int)(e % kp);
             const size_t o = ((size_t)l * a.Q + q) * kp + slot;
             s = a.in_s[o];
             r = a.in_r[o];
@@ -471,6 +495,14 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
             wave_sort64(s, r, lane);
         }
         const bool valid = lane < kp && r != SCAN_ROW_NONE;
+        if (a.out_s) {
+            if (lane < kp) {
+                const size_t o = ((size_t)blockIdx.y * a.Q + q) * kp + lane;
+                a.out_s[o] = valid ? s : SCAN_NEG_INF;
+                a.out_r[o] = valid ? r : -1;
+            }
+            return;
+        }
         if (lane < kp) a.cand[(size_t)q * a.cand_stride + a.page_off + lane] = valid ? r : -1;
         if (a.cur_s) {
             const unsigned long long m = __ballot(valid);

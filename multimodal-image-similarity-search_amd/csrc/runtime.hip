@@ -66,6 +66,21 @@ int mmiss_use_device(int device) {
     return MMISS_OK;
 }
 
+// ------------------------------------------------------------------ tuning options (tests / experiments)
+static std::mutex g_opt_mu;
+static std::map<std::string, int> g_opts;
+int mmiss_option(const char* key, int dflt) {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_opts.find(key);
+    return it == g_opts.end() ? dflt : it->second;
+}
+extern "C" int mmiss_dbg_set_option(const char* key, int value) {
+    if (!key) MM_FAIL(MMISS_ERR_ARG, "null option key");
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    g_opts[key] = value;
+    return MMISS_OK;
+}
+
 // ------------------------------------------------------------------ kernel timing
 namespace {
 struct ProfRec {

@@ -103,6 +103,23 @@ def test_batched_query_path_f16(mods, N, D, Q, k):
     _check(idx, ro, ro.normalize_rows(c, "f16"), labels, q, k)
 
 
+def test_batched_path_with_exact_duplicates(mods):
+    """Many identical rows spread over several 16-row groups: group maxima tie exactly, the k smallest labels win."""
+    FlatIndex, _, _, ro = mods
+    N, D, Q = 3000, 128, 20
+    c = _corpus(N, D, seed=5)
+    q = _corpus(Q, D, seed=6)
+    dup = np.concatenate([np.arange(40, 100), np.arange(700, 1000, 7), np.arange(2500, 2600)])
+    c[dup] = q[3]                    # > 200 rows identical to query 3
+    c[np.arange(1200, 1300)] = c[5]  # another duplicate cluster, not aligned with any query
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    stored = ro.normalize_rows(c, "f16")
+    for k in (1, 10, 24):
+        _check(idx, ro, stored, labels, q, k)
+
+
 def test_adversarial_order_ascending_similarity(mods):
     """Rows sorted so every later row beats all earlier ones: the running top-k' list is rewritten constantly."""
     FlatIndex, _, _, ro = mods
