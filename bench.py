@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--index-rows", type=int, default=100_000, help="rows per rank of the step's index")
     ap.add_argument("--retrieval-rows", type=int, default=10_000_000, help="total rows of the 10M x 512 f16 scan benchmark (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-text", action="store_true", help="skip the informational text-tower timing")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the instrumented replay (no roofline object)")
     return ap.parse_args()
 
@@ -180,9 +181,18 @@ def main():
         # the roofline numbers come from the launches sampled INSIDE the timed region; the replay gives the table
         top = timed_prof[0] if timed_prof else max(prof, key=lambda p: p["ms"])
         achieved = top["flops"] / top["ms"] / 1e9  # TFLOP/s: algorithmic flops per launch / mean launch duration
+        # HBM traffic per launch of that kernel: PMC counters cannot be read from inside this process; the value is
+        # the rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE measurement of the same command, kept in profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f).get(top["kernel"], {}).get("traffic_bytes")
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "kernel": top["kernel"], "symbol": KERNEL_SYMBOL.get(top["kernel"], top["kernel"]),
                     "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                     "sampled_launches_in_timed_region": top["launches"], "avg_launch_us": round(1e3 * top["ms"] / top["launches"], 2),
                     "flops_per_launch": top["flops"] / top["launches"]}
 
@@ -190,6 +200,29 @@ def main():
     retrieval = None
     if args.retrieval_rows > 0:
         retrieval = bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib)
+
+    # ---------------------------------------------------------------- text tower (BASELINE configs[2] inputs), informational
+    text = None
+    if not args.no_text:
+        rng = np.random.Generator(np.random.Philox(2 + rank))
+        ids = np.full((B, 77), 49407, dtype=np.int32)
+        ids[:, 0] = 49406
+        eos = rng.integers(2, 77, size=B)
+        body = rng.integers(0, 49406, size=(B, 77), dtype=np.int32)
+        for r in range(B):
+            ids[r, 1:eos[r]] = body[r, 1:eos[r]]
+        ids_d = torch.from_numpy(ids).to(dev)
+        temb = torch.empty(B, D, device=dev)
+        for _ in range(3):
+            enc.encode_text(ids_d, out=temb)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            enc.encode_text(ids_d, out=temb)
+        fence()
+        tdt = (time.perf_counter() - t0) / 10
+        text = {"texts_per_s": round(world * B / tdt, 1), "ms_per_batch": round(tdt * 1e3, 3), "batch": B, "tokens": 77,
+                "tflops": round(B * 5.960e9 / tdt / 1e12, 1), "flops_per_text": 5.960e9}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
@@ -211,7 +244,7 @@ def main():
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),
-            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
