@@ -50,6 +50,10 @@ int mmiss_dbg_encoder_record_taps(struct mmiss_encoder* enc, int on);
 /* 1 (default): LayerNorm is folded into the QKV / FC1 GEMMs; 0: separate LayerNorm kernels (A/B and parity tests) */
 int mmiss_dbg_encoder_set_fuse_ln(struct mmiss_encoder* enc, int on);
 
+/* experiment: full GEMM vs two half-M GEMMs (same stream / two streams); ms[3] per GEMM-equivalent */
+int mmiss_dbg_gemm_split_time(int device, int epi, int bm, const void* A, const void* W, void* out, const float* bias,
+                              int32_t M, int32_t N, int32_t K, int32_t iters, float* ms);
+
 /* process-wide integer tuning knob (A/B experiments from tools/): e.g. "scan_group" = 8 | 16 */
 int mmiss_dbg_set_option(const char* key, int value);
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "mmiss_dbg_encoder_record_taps": (_I, [_P, _I]),
     "mmiss_dbg_encoder_set_fuse_ln": (_I, [_P, _I]),
     "mmiss_dbg_set_option": (_I, [C.c_char_p, _I]),
+    "mmiss_dbg_gemm_split_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -675,3 +675,51 @@ extern "C" int mmiss_dbg_im2col(int device, void* hip_stream, const float* pixel
     MM_TRY(mmiss_use_device(device));
     return launch_im2col(reinterpret_cast<hipStream_t>(hip_stream), pixels, false, out, B, S, P, Kp);
 }
+
+
+// Experiment (tools/gemm_split_test.py): one GEMM over M rows vs two half-M GEMMs back to back vs the two halves on
+// two streams joined by events. ms[0..2] = milliseconds per GEMM-equivalent.
+extern "C" int mmiss_dbg_gemm_split_time(int device, int epi, int bm, const void* A, const void* W, void* out,
+                                         const float* bias, int32_t M, int32_t N, int32_t K, int32_t iters, float* ms) {
+    if (!A || !W || !out || !ms || iters <= 0 || (M % (2 * bm))) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_gemm_split_time: bad argument");
+    MM_TRY(mmiss_use_device(device));
+    hipStream_t s0, s1;
+    MM_HIP(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+    MM_HIP(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    hipEvent_t e0, e1, fork, join;
+    MM_HIP(hipEventCreate(&e0)); MM_HIP(hipEventCreate(&e1));
+    MM_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming)); MM_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    const int out_elt = (epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16) ? 2 : 4;
+    const int Mh = M / 2;
+    auto full = [&](hipStream_t s) -> int {
+        GemmEpi ep{}; ep.out = out; ep.bias = bias; ep.ldo = N; ep.m_valid = M;
+        return launch_gemm(s, epi, bm, A, W, ep, M, N, K);
+    };
+    auto half = [&](hipStream_t s, int which) -> int {
+        GemmEpi ep{}; ep.out = (char*)out + (size_t)which * Mh * N * out_elt; ep.bias = bias; ep.ldo = N; ep.m_valid = Mh;
+        return launch_gemm(s, epi, bm, (const char*)A + (size_t)which * Mh * K * 2, W, ep, Mh, N, K);
+    };
+    for (int mode = 0; mode < 3; ++mode) {
+        for (int it = -3; it < iters; ++it) {
+            if (it == 0) MM_HIP(hipEventRecord(e0, s0));
+            if (mode == 0) { MM_TRY(full(s0)); }
+            else if (mode == 1) { MM_TRY(half(s0, 0)); MM_TRY(half(s0, 1)); }
+            else {
+                MM_HIP(hipEventRecord(fork, s0));
+                MM_HIP(hipStreamWaitEvent(s1, fork, 0));
+                MM_TRY(half(s0, 0));
+                MM_TRY(half(s1, 1));
+                MM_HIP(hipEventRecord(join, s1));
+                MM_HIP(hipStreamWaitEvent(s0, join, 0));
+            }
+        }
+        MM_HIP(hipEventRecord(e1, s0));
+        MM_HIP(hipEventSynchronize(e1));
+        float t = 0.f;
+        MM_HIP(hipEventElapsedTime(&t, e0, e1));
+        ms[mode] = t / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
+    (void)hipStreamDestroy(s0); (void)hipStreamDestroy(s1);
+    return MMISS_OK;
+}
