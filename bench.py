@@ -224,6 +224,34 @@ def main():
         text = {"texts_per_s": round(world * B / tdt, 1), "ms_per_batch": round(tdt * 1e3, 3), "batch": B, "tokens": 77,
                 "tflops": round(B * 5.960e9 / tdt / 1e12, 1), "flops_per_text": 5.960e9}
 
+    # ---------------------------------------------------------------- the reference's own regime: one request at a time
+    latency = None
+    if rank == 0 and not args.no_text:
+        one_px = pixels[:1].contiguous()
+        one_emb = torch.empty(1, D, device=dev)
+
+        def one_image_query():
+            enc.encode_image(one_px, out=one_emb)
+            return index.query(one_emb, K_TOP)
+
+        for _ in range(5):
+            one_image_query()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            one_image_query()
+        torch.cuda.synchronize()
+        img_ms = (time.perf_counter() - t0) / 50 * 1e3
+        host_px = one_px.cpu().numpy()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            e1 = enc.encode_image(host_px)            # host pixels in, host embedding out (PCIe both ways + sync)
+            index.query(e1, K_TOP)
+        host_ms = (time.perf_counter() - t0) / 20 * 1e3
+        latency = {"image_encode_plus_top10_ms_device_resident": round(img_ms, 3),
+                   "image_encode_plus_top10_ms_host_buffers": round(host_ms, 3), "batch": 1,
+                   "note": "the reference runs batch 1 on the CPU (backend/app/utils.py:76-77)"}
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -244,7 +272,7 @@ def main():
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),
-            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

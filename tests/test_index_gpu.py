@@ -245,3 +245,92 @@ def test_merge_topk_equals_unsharded(mods):
     np.testing.assert_array_equal(ml, ol)
     np.testing.assert_array_equal(md.view(np.uint32), od.view(np.uint32))
     np.testing.assert_array_equal(mc, oc)
+
+
+def test_config3_text_queries_against_image_index():
+    """BASELINE configs[2] at reduced size: random 77-token prompts -> text tower -> top-10 over a 200k x 512 index."""
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from mmiss_amd.index import FlatIndex
+    from oracle import clip_oracle as co
+    from oracle import retrieval_oracle as ro
+
+    s = co.TINY
+    W = co.init_weights(s, seed=2)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_text=64, max_batch_image=8)
+    enc.load_state_dict(W)
+    ids = co.synthetic_text_ids(200, s.t_ctx, s.t_vocab, s.eos_token_id, seed=3)
+    q = enc.encode_text(ids)  # [200, 128], chunked over max_batch_text
+    assert (1 - (q * co.embed_texts(ids, W, s)).sum(1)).max() < 1e-3
+    N = 200_000
+    c = _corpus(N, s.proj_dim, seed=4)
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(s.proj_dim, "f16")
+    idx.add(c, labels)
+    lab, dist, cnt = idx.query(q, 10)
+    # the oracle on the SAME query bits: ids and distances bit-exact (checked on a subset to keep the CPU side short)
+    sub = np.arange(0, 200, 17)
+    ol, od, oc = ro.query(q[sub], ro.normalize_rows(c, "f16"), labels, 10)
+    np.testing.assert_array_equal(lab[sub], ol)
+    np.testing.assert_array_equal(dist[sub].view(np.uint32), od.view(np.uint32))
+    assert (np.diff(dist, axis=1) >= 0).all() and (cnt == 10).all()
+
+
+def test_config4_sharded_multimodal_batch():
+    """BASELINE configs[3] at reduced size: 8 logical row shards, batched (image+text average) queries, per-shard
+    top-10, shard merge == the unsharded index, bit for bit."""
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.index import FlatIndex, blend, merge_topk
+    from oracle import retrieval_oracle as ro
+
+    N, D, S, Q, k = 160_000, 512, 8, 96, 10
+    c = _corpus(N, D, seed=14)
+    labels = np.arange(N, dtype=np.int64)
+    qi, qt = _corpus(Q, D, seed=15), _corpus(Q, D, seed=16)
+    q = blend(qi, qt, 0.5)
+    np.testing.assert_array_equal(q.view(np.uint32), ro.blend(qi, qt, 0.5).view(np.uint32))
+    whole = FlatIndex(D, "f16")
+    whole.add(c, labels)
+    full = whole.query(q, k)
+    per = N // S
+    ls, ds = [], []
+    for s_ in range(S):
+        sh = FlatIndex(D, "f16")
+        sh.add(c[s_ * per:(s_ + 1) * per], labels[s_ * per:(s_ + 1) * per])
+        l, d, _ = sh.query(q, k)
+        ls.append(l)
+        ds.append(d)
+    ml, md, mc = merge_topk(np.stack(ds), np.stack(ls))
+    np.testing.assert_array_equal(ml, full[0])
+    np.testing.assert_array_equal(md.view(np.uint32), full[1].view(np.uint32))
+    sub = np.arange(0, Q, 13)
+    ol, od, _ = ro.query(q[sub], ro.normalize_rows(c, "f16"), labels, k)
+    np.testing.assert_array_equal(ml[sub], ol)
+
+
+def test_full_size_properties_1m_rows():
+    """Size-independent properties at 1M x 512 (oracle too slow there): every row finds itself first at distance ~0,
+    results are sorted, counts are k, a query batch equals the same queries one by one, f16 and Q>16 paths agree."""
+    import torch
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.index import FlatIndex
+
+    N, D = 1_000_000, 512
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rows = torch.randn(N, D, device="cuda", generator=g)
+    idx = FlatIndex(D, "f16", capacity=N)
+    idx.add(rows, np.arange(N, dtype=np.int64))
+    assert idx.count() == N
+    probe = torch.randint(0, N, (48,), generator=torch.Generator().manual_seed(2))
+    q = rows[probe.cuda()]
+    lab, dist, cnt = idx.query(q, 10)                      # Q = 48 -> score-GEMM path
+    lab, dist = lab.cpu().numpy(), dist.cpu().numpy()
+    assert (lab[:, 0] == probe.numpy()).all()
+    assert np.abs(dist[:, 0]).max() < 2e-3                 # f16 storage rounding of a unit vector
+    assert (np.diff(dist, axis=1) >= 0).all() and (cnt.cpu().numpy() == 10).all()
+    for j in range(0, 48, 9):                              # Q = 1 -> streaming scan path: identical results
+        l1, d1, _ = idx.query(q[j:j + 1], 10)
+        np.testing.assert_array_equal(l1.cpu().numpy()[0], lab[j])
+        np.testing.assert_array_equal(d1.cpu().numpy()[0].view(np.uint32), dist[j].view(np.uint32))
+    l16, d16, _ = idx.query(q[:16], 10)                    # Q = 16 -> scan path with a full MFMA tile of queries
+    np.testing.assert_array_equal(l16.cpu().numpy(), lab[:16])
