@@ -75,11 +75,30 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()  # (the gloo dry run puts several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("MMISS_DIST_BACKEND", "nccl")  # "gloo" = dry run of the N>1 control flow on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_gather(out, inp):
+        """all_gather_into_tensor on device tensors (RCCL); the gloo dry run stages through host memory."""
+        if backend == "nccl":
+            dist.all_gather_into_tensor(out, inp)
+        else:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+
+    def all_reduce_max(x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     import mmiss_amd  # noqa: F401
     from mmiss_amd import _lib
@@ -103,12 +122,12 @@ def main():
     def step():
         enc.encode_image(pixels, out=emb)
         if world > 1:
-            dist.all_gather_into_tensor(emb_all, emb)
+            all_gather(emb_all, emb)
             lab, dst, _ = index.query(emb_all, K_TOP)
             lab_all = torch.empty((world * lab.shape[0], lab.shape[1]), dtype=lab.dtype, device=dev)
             dst_all = torch.empty((world * dst.shape[0], dst.shape[1]), dtype=dst.dtype, device=dev)
-            dist.all_gather_into_tensor(lab_all, lab)
-            dist.all_gather_into_tensor(dst_all, dst)
+            all_gather(lab_all, lab)
+            all_gather(dst_all, dst)
             return merge_topk(dst_all.view(world, *dst.shape), lab_all.view(world, *lab.shape))
         return index.query(emb, K_TOP)
 
@@ -162,9 +181,7 @@ def main():
         _lib.prof_enable(False)
         prof = _lib.prof_read()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = all_reduce_max(elapsed)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * args.steps / elapsed
 
@@ -199,7 +216,8 @@ def main():
     # ---------------------------------------------------------------- 10M x 512 f16 scan (second half of the metric)
     retrieval = None
     if args.retrieval_rows > 0:
-        retrieval = bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib)
+        retrieval = bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib,
+                                    all_gather, all_reduce_max)
 
     # ---------------------------------------------------------------- text tower (BASELINE configs[2] inputs), informational
     text = None
@@ -279,7 +297,8 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib):
+def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib, all_gather,
+                    all_reduce_max):
     """cosine top-10 over N x 512 f16 rows sharded over the ranks; Q=1 (HBM-bound) and Q=1024."""
     N, D, K_TOP = args.retrieval_rows, 512, 10
     per = N // world
@@ -298,8 +317,8 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
             if world > 1:
                 lab_all = torch.empty((world * lab.shape[0], lab.shape[1]), dtype=lab.dtype, device=dev)
                 dst_all = torch.empty((world * dst.shape[0], dst.shape[1]), dtype=dst.dtype, device=dev)
-                dist.all_gather_into_tensor(lab_all, lab)
-                dist.all_gather_into_tensor(dst_all, dst)
+                all_gather(lab_all, lab)
+                all_gather(dst_all, dst)
                 return merge_topk(dst_all.view(world, *dst.shape), lab_all.view(world, *lab.shape))
             return lab, dst
 
@@ -319,9 +338,7 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
         _lib.prof_enable(False)
         prof = {p["kernel"]: p for p in _lib.prof_read()}
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt = all_reduce_max(dt)
         scan = prof.get("scan_topk_f16")
         entry = {"ms_per_batch": round(dt * 1e3, 3), "mvec_per_s": round(N / dt / 1e6, 1),
                  "gpairs_per_s": round(Q * N / dt / 1e9, 2),
