@@ -3,6 +3,7 @@
 #include "common.h"
 #include "gemm_bf16.h"
 #include "gemm_bf16_256.h"
+#include "gemm_bf16_ring.h"
 #include "encoder_kernels.h"
 #include <map>
 #include <set>
@@ -624,6 +625,7 @@ extern "C" int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant
     GemmEpi ep{};
     ep.out = out; ep.bias = bias; ep.aux = aux; ep.ldo = N; ep.m_valid = M; ep.p0 = p0; ep.p1 = p1;
     if (variant == 256) return launch_gemm256(reinterpret_cast<hipStream_t>(hip_stream), epi, A, W, ep, M, N, K);
+    if (variant > 1000) return launch_gemm_ring(reinterpret_cast<hipStream_t>(hip_stream), epi, variant - 1000, A, W, ep, M, N, K);
     return launch_gemm(reinterpret_cast<hipStream_t>(hip_stream), epi, variant, A, W, ep, M, N, K);
 }
 
@@ -639,6 +641,7 @@ extern "C" int mmiss_dbg_gemm_time(int device, int epi, int variant, const void*
     MM_HIP(hipEventCreate(&e1));
     auto run = [&]() -> int {
         if (variant == 256) return launch_gemm256(nullptr, epi, A, W, ep, M, N, K);
+        if (variant > 1000) return launch_gemm_ring(nullptr, epi, variant - 1000, A, W, ep, M, N, K);
         return launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K);
     };
     for (int i = 0; i < 3; ++i) MM_TRY(run());

@@ -17,10 +17,11 @@ shapes = [("qkv", _lib.EPI_BIAS_BF16, 2304, 768), ("out", _lib.EPI_BIAS_RESID_F3
           ("fc1", _lib.EPI_BIAS_QGELU_BF16, 3072, 768), ("fc2", _lib.EPI_BIAS_RESID_F32, 768, 3072)]
 res = []
 for name, epi, N, K in shapes:
-    for bm in (128, 160, 192, 256):
+    for bm in (128, 160, 192, 256, 1128, 1160, 1192):
         if bm == 256 and N % 256:
             continue
-        M = (M0 + bm - 1) // bm * bm
+        tile = bm % 1000
+        M = (M0 + tile - 1) // tile * tile
         A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
         W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
         bias = torch.randn(N, device="cuda")

@@ -9,8 +9,10 @@ lib = _lib.load()
 M0 = 12800
 for name, epi, N, bm in [("resid N768 bm160", _lib.EPI_BIAS_RESID_F32, 768, 160), ("bias_bf16 N2304 bm192", _lib.EPI_BIAS_BF16, 2304, 192),
                          ("bias_bf16 N2304 bm256", _lib.EPI_BIAS_BF16, 2304, 256), ("qgelu N3072 bm192", _lib.EPI_BIAS_QGELU_BF16, 3072, 192),
-                         ("f32 N768 bm160", _lib.EPI_F32, 768, 160)]:
-    M = (M0 + bm - 1) // bm * bm
+                         ("f32 N768 bm160", _lib.EPI_F32, 768, 160),
+                         ("RING resid N768 bm160", _lib.EPI_BIAS_RESID_F32, 768, 1160), ("RING bias_bf16 N2304 bm192", _lib.EPI_BIAS_BF16, 2304, 1192),
+                         ("RING qgelu N3072 bm192", _lib.EPI_BIAS_QGELU_BF16, 3072, 1192)]:
+    M = (M0 + bm % 1000 - 1) // (bm % 1000) * (bm % 1000)
     line = []
     for K in (64, 128, 256, 768, 1536, 3072):
         A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
