@@ -185,3 +185,65 @@ def test_b32_image_and_text_embeddings(b32):
     out_t = enc.encode_text(ids)
     ref_t = co.embed_texts(ids, W, s)
     assert (1 - _cos(out_t, ref_t)).max() < COS_TOL
+
+
+def test_longclip_l14_geometry_two_layers():
+    """The reference HEAD's model family (ViT-L/14 towers, 248-token text table, 768-d joint space; utils.py:16-17)
+    with the depth cut to 2 layers to keep the oracle fast: d=1024/16 heads/T=257 vision, d=768/12 heads/T=248 text."""
+    import dataclasses
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.LONGCLIP_L14, v_layers=2, t_layers=2, t_vocab=2000, eos_token_id=1999)
+    W = co.init_weights(s, seed=21)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=4, max_batch_text=4)
+    enc.load_state_dict(W)
+    rng = np.random.Generator(np.random.Philox(22))
+    px = rng.standard_normal((3, 3, 224, 224), dtype=np.float32)
+    out = enc.encode_image(px)
+    assert out.shape == (3, 768)
+    assert (1 - _cos(out, co.embed_images(px, W, s))).max() < COS_TOL
+    ids = co.synthetic_text_ids(3, 248, s.t_vocab, s.eos_token_id, seed=23)
+    assert (1 - _cos(enc.encode_text(ids), co.embed_texts(ids, W, s))).max() < COS_TOL
+
+
+def test_concurrent_queries_and_updates_on_one_collection():
+    """The reference mutates the collection from a background task while routes read it (main.py:410,1030): one writer
+    thread and two reader threads on the same FlatCollection must not corrupt results."""
+    import threading
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.collection import FlatCollection
+
+    col = FlatCollection("threads", autosave=False)
+    rng = np.random.Generator(np.random.Philox(31))
+    base = rng.standard_normal((64, 128), dtype=np.float32)
+    col.add(ids=[f"b{i}" for i in range(64)], embeddings=base, metadatas=[{"n": i} for i in range(64)])
+    errors = []
+
+    def writer():
+        try:
+            for i in range(40):
+                col.add(ids=[f"w{i}"], embeddings=rng.standard_normal((1, 128), dtype=np.float32), metadatas=[{"n": 100 + i}])
+                col.update(ids=[f"b{i}"], metadatas=[{"touched": True}])
+                if i % 5 == 4:
+                    col.delete(ids=[f"w{i - 2}"])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    def reader(seed):
+        try:
+            for i in range(60):
+                j = (seed * 7 + i) % 64
+                res = col.query(query_embeddings=base[j:j + 1], n_results=3, include=["metadatas", "distances"])
+                assert res["ids"][0][0] == f"b{j}" and res["distances"][0][0] < 1e-5
+                assert res["metadatas"][0][0]["n"] == j
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=writer)] + [threading.Thread(target=reader, args=(s_,)) for s_ in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert col.count() == 64 + 40 - 8
