@@ -197,14 +197,25 @@ class ClipEncoder:
         _lib.check(fn(self._h, _lib.ptr(pixels), B, _lib.ptr(out)))
         return out
 
-    def encode_text(self, input_ids, out=None):
-        """input_ids: int [B,T] (T <= context length), rows = BOS ... EOS, padding -> float32 [B,proj] unit rows."""
+    def encode_text(self, input_ids, out=None, trim_padding: bool = True):
+        """input_ids: int [B,T] (T <= context length), rows = BOS ... EOS, padding -> float32 [B,proj] unit rows.
+
+        trim_padding: the pooled row is the first EOS and attention is causal, so columns after the LAST row's EOS
+        cannot influence any output; they are dropped before the tower runs (the reference pads every query to 248
+        tokens, backend/app/utils.py:88 — a 10-token prompt then costs 10/248 of the padded work). Host arrays only;
+        device tensors are taken as they are (no sync to inspect them)."""
         if _is_torch(input_ids):
             import torch
 
             ids = input_ids.to(torch.int32).contiguous()
         else:
             ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+            if trim_padding and ids.ndim == 2 and ids.shape[0] > 0:
+                eos = self.shape.eos_token_id
+                pos = ids.argmax(axis=1) if eos == 2 else (ids == eos).argmax(axis=1)
+                has = np.ones(ids.shape[0], bool) if eos == 2 else (ids == eos).any(axis=1)
+                if has.all():
+                    ids = np.ascontiguousarray(ids[:, : int(pos.max()) + 1])
         if ids.ndim != 2:
             raise ValueError("input_ids must be [B,T]")
         B, T = int(ids.shape[0]), int(ids.shape[1])

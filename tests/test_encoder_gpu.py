@@ -247,3 +247,15 @@ def test_concurrent_queries_and_updates_on_one_collection():
         t.join()
     assert not errors, errors
     assert col.count() == 64 + 40 - 8
+
+
+def test_text_padding_is_trimmed_without_changing_results(tiny):
+    enc, W, co = tiny
+    s = co.TINY
+    ids = co.synthetic_text_ids(5, s.t_ctx, s.t_vocab, s.eos_token_id, seed=41)
+    ids[:, 6:] = s.eos_token_id          # short prompts padded to the full context, as the reference does
+    ids[:, 5] = s.eos_token_id
+    a = enc.encode_text(ids)              # runs at T = 6
+    b = enc.encode_text(ids, trim_padding=False)
+    assert (1 - _cos(a, b)).max() < 1e-6
+    assert (1 - _cos(a, co.embed_texts(ids, W, s))).max() < COS_TOL
