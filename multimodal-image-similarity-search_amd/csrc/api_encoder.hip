@@ -36,6 +36,7 @@ __global__ void gather_rows16_kernel(const char* __restrict__ src, const int32_t
 
 struct LayerW {
     DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, ln2g, ln2b, w1, b1, w2, b2;
+    DevBuf wqkv_f, cqkv, bqkv_f, w1_f, c1, b1_f;  // LayerNorm folded into the QKV / FC1 weights (finalize)
 };
 
 struct Tower {
@@ -49,6 +50,7 @@ struct Tower {
     DevBuf x, h, qkv, ctx, u, pooled, proj_out, pool_row, out_stage, taps;
     DevBuf xc, hc, ctxc, uc;  // compact [Bp, *] buffers of the pooled rows (last-layer pruning)
     DevBuf stats;             // [Mp][hidden/64][2] partial row (sum, sumsq) for the LayerNorm-fused GEMMs
+    DevBuf xb;                // bf16 copy of the residual stream (A operand of the LayerNorm-folded GEMMs)
     bool pooled_compact = false;
     int last_B = 0, last_T = 0;
     int64_t tap_stride = 0;  // floats per recorded tap
@@ -74,10 +76,16 @@ struct mmiss_encoder {
     std::mutex mu;
     bool finalized = false;
     bool record_taps = false;
-    // LayerNorm folded into the QKV / FC1 GEMM A-operand staging. Correct, but measured SLOWER at B=256 (every one of
-    // the 18-24 column blocks re-normalises its f32 rows through registers: 342-371 TF vs 768-843 TF + a 14 us
-    // LayerNorm pass), so it is off by default and kept as an option for small batches / later rework.
-    bool fuse_ln = false;
+    // How LayerNorm1/2 reach the QKV / FC1 GEMMs:
+    //   0 separate LayerNorm kernels (x f32 -> h bf16);
+    //   1 normalised while the f32 rows are staged as the A operand (correct, but SLOWER at B=256: every one of the
+    //     18-24 column blocks re-normalises its rows through registers, 342-371 TF);
+    //   2 folded algebraically: A = bf16(x) written by the residual epilogues, gamma folded into the weights, the
+    //     (mean, rstd) correction applied in the GEMM epilogue — no LayerNorm pass at all. Same precision
+    //     (1-cos 5e-6 either way), and at B=256 the same speed: the 2 x 13.8 us LayerNorm passes it removes per layer
+    //     come back as +9 / +4 / 2 x +6 us in the FC1 / QKV / residual epilogues (profiles/gemm_variants_r01.md).
+    // Default: 0, the simplest of three equally fast ways.
+    int ln_mode = 0;
 
     Tower vis, txt;
     // vision-only
@@ -174,6 +182,7 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     MM_TRY(alloc_zero(tw.ctxc, (size_t)Bp * d * 2));
     MM_TRY(alloc_zero(tw.uc, (size_t)Bp * tw.mlp * 2));
     MM_TRY(alloc_zero(tw.stats, (size_t)Mp * (d / 64) * 2 * 4));
+    MM_TRY(alloc_zero(tw.xb, (size_t)Mp * d * 2));
     if (e->record_taps) {
         tw.tap_stride = Mp * d;
         MM_TRY(alloc_zero(tw.taps, (size_t)(tw.layers + 1) * tw.tap_stride * 4));
@@ -201,19 +210,24 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // rows only (compacted). Kept off while taps are recorded so the tests can compare every row of every layer.
     const bool prune = !e->record_taps;
     tw.pooled_compact = false;
-    const bool fuse = e->fuse_ln;
+    const int mode = e->ln_mode;
+    const bool fuse = mode == 1, fold = mode == 2;
     const int parts = d / 64;
-    if (fuse) {
-        MM_PROF("row_stats", st, 3.0 * M * d, 4.0 * M * d);
-        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(), M,
-                           d, parts);
+    if (fuse || fold) {
+        MM_PROF("row_stats", st, 3.0 * M * d, (fold ? 6.0 : 4.0) * M * d);
+        hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(),
+                           fold ? tw.xb.as<uint16_t>() : nullptr, M, d, parts);
         MM_HIP(hipGetLastError());
     }
     for (int l = 0; l < tw.layers; ++l) {
         LayerW& L = tw.L[l];
         GemmEpi ep{};
         ep.out = tw.qkv.p; ep.bias = L.bqkv.as<float>(); ep.ldo = 3 * d; ep.m_valid = M;
-        if (fuse) {
+        if (fold) {
+            ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
+            ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
+            MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_BF16, bm_qkv, tw.xb.p, L.wqkv_f.p, ep, padded(bm_qkv), 3 * d, d));
+        } else if (fuse) {
             ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln1g.as<float>(); ep.ln_b = L.ln1b.as<float>();
             ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.x.as<float>(), L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
@@ -247,11 +261,16 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = M;
-        ep.stats_out = fuse ? tw.stats.as<float>() : nullptr;  // row statistics of the new residual for LN2
+        ep.stats_out = (fuse || fold) ? tw.stats.as<float>() : nullptr;  // row statistics of the new residual for LN2
+        ep.xb_out = fold ? tw.xb.p : nullptr;
         MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         ep = GemmEpi{};
         ep.out = tw.u.p; ep.bias = L.b1.as<float>(); ep.ldo = tw.mlp; ep.m_valid = M;
-        if (fuse) {
+        if (fold) {
+            ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
+            ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
+            MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, bm_mlp, tw.xb.p, L.w1_f.p, ep, padded(bm_mlp), tw.mlp, d));
+        } else if (fuse) {
             ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln2g.as<float>(); ep.ln_b = L.ln2b.as<float>();
             ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.x.as<float>(), L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
@@ -262,7 +281,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = M;
-        ep.stats_out = fuse ? tw.stats.as<float>() : nullptr;  // ... and for the next layer's LN1
+        ep.stats_out = (fuse || fold) ? tw.stats.as<float>() : nullptr;  // ... and for the next layer's LN1
+        ep.xb_out = fold ? tw.xb.p : nullptr;
         MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         MM_TRY(tap(l + 1));
     }
@@ -484,6 +504,23 @@ extern "C" int mmiss_encoder_finalize(mmiss_encoder* enc) {
     if (n_missing)
         MM_FAIL(MMISS_ERR_STATE, "mmiss_encoder_finalize: %d weight tensors missing (%s%s)", n_missing, missing.c_str(),
                 n_missing > 4 ? ", ..." : "");
+    // fold LayerNorm1 / LayerNorm2 into the QKV / FC1 weights (ln_mode 2)
+    MM_TRY(mmiss_use_device(enc->device));
+    for (Tower* tw : {&enc->vis, &enc->txt}) {
+        const int d = tw->hidden;
+        for (LayerW& L : tw->L) {
+            MM_TRY(L.wqkv_f.alloc((size_t)3 * d * d * 2)); MM_TRY(L.cqkv.alloc((size_t)3 * d * 4)); MM_TRY(L.bqkv_f.alloc((size_t)3 * d * 4));
+            MM_TRY(L.w1_f.alloc((size_t)tw->mlp * d * 2)); MM_TRY(L.c1.alloc((size_t)tw->mlp * 4)); MM_TRY(L.b1_f.alloc((size_t)tw->mlp * 4));
+            hipLaunchKernelGGL(fold_ln_weights_kernel, dim3((3 * d + 3) / 4), dim3(256), 0, enc->own_stream, L.wqkv.as<uint16_t>(),
+                               L.ln1g.as<float>(), L.ln1b.as<float>(), L.bqkv.as<float>(), L.wqkv_f.as<uint16_t>(),
+                               L.cqkv.as<float>(), L.bqkv_f.as<float>(), 3 * d, d);
+            hipLaunchKernelGGL(fold_ln_weights_kernel, dim3((tw->mlp + 3) / 4), dim3(256), 0, enc->own_stream, L.w1.as<uint16_t>(),
+                               L.ln2g.as<float>(), L.ln2b.as<float>(), L.b1.as<float>(), L.w1_f.as<uint16_t>(),
+                               L.c1.as<float>(), L.b1_f.as<float>(), tw->mlp, d);
+        }
+    }
+    MM_HIP(hipGetLastError());
+    MM_HIP(hipStreamSynchronize(enc->own_stream));
     enc->finalized = true;
     return MMISS_OK;
 }
@@ -567,7 +604,7 @@ extern "C" int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t
 extern "C" int mmiss_dbg_encoder_set_fuse_ln(mmiss_encoder* enc, int on) {
     if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
     std::lock_guard<std::mutex> lk(enc->mu);
-    enc->fuse_ln = on != 0;
+    enc->ln_mode = on < 0 ? 0 : (on > 2 ? 2 : on);  // 0 separate kernels, 1 operand-fused, 2 folded (default)
     return MMISS_OK;
 }
 

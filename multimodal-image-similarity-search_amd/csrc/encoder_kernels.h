@@ -180,8 +180,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // Row statistics for the LayerNorm-fused GEMM (gemm_bf16.h, ALN): stats[r][0] = (sum, sumsq) of row r, the other
 // parts zero. Only needed once per forward (the embeddings); afterwards the residual GEMM epilogues produce them.
-__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int M,
-                                                        int d, int parts) {
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                        uint16_t* __restrict__ xb, int M, int d, int parts) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -191,11 +191,40 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
         const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
         s += (v[0] + v[1]) + (v[2] + v[3]);
         q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        if (xb) {  // bf16 copy of the row: the A operand of the LayerNorm-folded GEMMs
+            u32x2 pk;
+            pk[0] = pack_bf16x2(v[0], v[1]);
+            pk[1] = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(xb + (size_t)r * d + c) = pk;
+        }
     }
     s = wave_sum(s);
     q = wave_sum(q);
     float* o = stats + (size_t)r * parts * 2;
     for (int i = lane; i < parts * 2; i += 64) o[i] = (i == 0) ? s : (i == 1 ? q : 0.f);
+}
+
+// LayerNorm folding (gemm_bf16.h, epilogues 7/8): W'[n,k] = bf16(W[n,k] * gamma[k]), c[n] = sum_k W'[n,k],
+// b'[n] = b[n] + sum_k beta[k] * W[n,k]. One wave per output feature n; run once when the weights are finalised.
+__global__ __launch_bounds__(256) void fold_ln_weights_kernel(const uint16_t* __restrict__ Wb, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ bias,
+                                                              uint16_t* __restrict__ Wf, float* __restrict__ cvec,
+                                                              float* __restrict__ bf, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float c = 0.f, bs = 0.f;
+    for (int kk = lane; kk < K; kk += 64) {
+        const float w = bf16_bits_to_f32(Wb[(size_t)n * K + kk]);
+        const bf16_t wf = (bf16_t)(w * gamma[kk]);
+        const uint16_t bits = __builtin_bit_cast(uint16_t, wf);
+        Wf[(size_t)n * K + kk] = bits;
+        c += bf16_bits_to_f32(bits);
+        bs += beta[kk] * w;
+    }
+    c = wave_sum(c);
+    bs = wave_sum(bs);
+    if (lane == 0) { cvec[n] = c; bf[n] = bias[n] + bs; }
 }
 
 // ------------------------------------------------------------------------------------------------

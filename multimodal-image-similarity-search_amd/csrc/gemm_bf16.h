@@ -35,9 +35,15 @@ struct GemmEpi {
     float ln_eps;
     // BIAS_RESID_F32: if set, partial (sum, sumsq) of the NEW residual rows, [M][N/64][2] — the next LayerNorm's input
     float* stats_out;
+    void* xb_out;           // BIAS_RESID_F32: if set, bf16 copy of the new residual rows [M, ldo] (next GEMM's A operand)
 };
 
 #define MMISS_EPI_GROUPMAX_F32 5  // internal: out f32 [M, N/16] = max over the lane's 16 n (see decode below)
+// internal: LayerNorm folded into the GEMM algebraically. A = bf16(x) (raw residual rows), W' = bf16(W * gamma),
+//   LN(x) W^T + b = rstd_m * (x W'^T - mean_m * c_n) + b'_n,   c_n = sum_k W'[n,k],  b'_n = b_n + sum_k beta_k W[n,k]
+// (mean_m, rstd_m from ep.ln_stats; c in ep.aux; b' in ep.bias). 7: bf16 out, 8: + QuickGELU.
+#define MMISS_EPI_LNFOLD_BF16 7
+#define MMISS_EPI_LNFOLD_QGELU_BF16 8
 
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -92,26 +98,56 @@ template <> struct MfmaIn<_Float16> {
 
 template <int EPI, int JT>
 __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4][JT], int m_wave, int n_wave, char* patch,
-                                              int lane) {
+                                              int lane, char* stat_area = nullptr) {
     const int fr = lane & 15, fg = lane >> 4;
     const int rrow = lane >> 3, rchunk = lane & 7;  // read-back role: row (of 8) and 16-byte chunk (of 8)
-    constexpr bool OUT_BF16 = (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16);
-    f32x4 bias[4];
-    if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
+    constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
+    constexpr bool OUT_BF16 = (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || FOLD);
+    f32x4 bias[4], cvec[4];
+    if constexpr (OUT_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + n_wave + i * 16 + 4 * fg);
+    }
+    float* sstat = nullptr;
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cvec[i] = *reinterpret_cast<const f32x4*>(ep.aux + n_wave + i * 16 + 4 * fg);
+        // per-row (mean, rstd) of this wave's JT*16 rows from the partial sums, kept in LDS next to the patch
+        sstat = reinterpret_cast<float*>(stat_area);
+        for (int r = lane; r < JT * 16; r += 64) {
+            // the row's partial sums are contiguous (parts x (sum, sumsq)); vector loads, all issued before the adds
+            const f32x4* st = reinterpret_cast<const f32x4*>(ep.ln_stats + (size_t)(m_wave + r) * ep.ln_parts * 2);
+            const int n4 = ep.ln_parts >> 1;  // hidden % 128 == 0 -> parts is even
+            float s1 = 0.f, s2 = 0.f;
+            f32x4 buf[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) buf[q] = (q < n4) ? st[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s1 += buf[q][0] + buf[q][2]; s2 += buf[q][1] + buf[q][3]; }
+            const float kd = (float)(ep.ln_parts * 64);
+            const float mean = s1 / kd;
+            const float var = fmaxf(s2 / kd - mean * mean, 0.f);
+            sstat[2 * r] = mean;
+            sstat[2 * r + 1] = 1.0f / sqrtf(var + ep.ln_eps);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         // ---- transpose-in: lane (fr = row, fg) owns columns i*16 + 4*fg .. +3
         if constexpr (OUT_BF16) {
+            float mu = 0.f, rstd = 1.f;
+            if constexpr (FOLD) { mu = sstat[2 * (j * 16 + fr)]; rstd = sstat[2 * (j * 16 + fr) + 1]; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float y[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    y[r] = acc[i][j][r] + bias[i][r];
-                    if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[r] = quick_gelu(y[r]);
+                    if constexpr (FOLD) y[r] = rstd * (acc[i][j][r] - mu * cvec[i][r]) + bias[i][r];
+                    else y[r] = acc[i][j][r] + bias[i][r];
+                    if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16) y[r] = quick_gelu(y[r]);
                 }
                 u32x2 pk;
                 pk[0] = pack_bf16x2(y[0], y[1]);
@@ -151,6 +187,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
                             float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
                             v = *reinterpret_cast<const f32x4*>(p) + v;
                             *reinterpret_cast<f32x4*>(p) = v;
+                            if (ep.xb_out) {
+                                u32x2 pk;
+                                pk[0] = pack_bf16x2(v[0], v[1]);
+                                pk[1] = pack_bf16x2(v[2], v[3]);
+                                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(ep.xb_out) + (size_t)m * ep.ldo + n) = pk;
+                            }
                             rs += (v[0] + v[1]) + (v[2] + v[3]);
                             rq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                         } else if constexpr (EPI == MMISS_EPI_PATCH_F32) {
@@ -350,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
     }
 
     // all waves are past the loop's last barrier: the staging buffers are dead, each wave takes a private patch
-    gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / 2), bn * GEMM_BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane);
+    gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / 2), bn * GEMM_BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
+                           smem + 4 * EPI_PATCH_BYTES + wave * (JT * 16 * 8));
 }
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
@@ -388,6 +431,32 @@ static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const 
                        reinterpret_cast<const IN*>(W), M, N, K, ep);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
+}
+
+// LayerNorm-folded bf16 GEMM (epilogues 7 / 8): A = bf16 residual rows, W = gamma-folded weights, ep.aux = c,
+// ep.bias = b', ep.ln_stats / ln_parts / ln_eps = the rows' partial statistics.
+static int launch_gemm_fold(hipStream_t st, int epi, int bm, const void* A, const void* W, const GemmEpi& ep, int M, int N,
+                            int K) {
+    if (bm == 0) bm = 128;
+    if (M <= 0 || N <= 0 || K <= 0 || (M % bm) || (N % GEMM_BN) || (K % GEMM_BK) || !ep.ln_stats || !ep.aux || !ep.bias ||
+        ep.ln_parts * 64 != K)
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm_fold: M=%d N=%d K=%d bm=%d parts=%d", M, N, K, bm, ep.ln_parts);
+    const int mv = ep.m_valid < M ? ep.m_valid : M;
+    const double bytes = 2.0 * ((double)mv * K + (double)N * K) + 2.0 * (double)mv * N;
+    MM_PROF(epi == MMISS_EPI_LNFOLD_BF16 ? "gemm_bf16_lnfold_bias" : "gemm_bf16_lnfold_qgelu", st, 2.0 * mv * N * K, bytes);
+#define GEMM_FOLD_CASE(BMV)                                                                                        \
+    case BMV:                                                                                                      \
+        return epi == MMISS_EPI_LNFOLD_BF16                                                                        \
+                   ? launch_gemm_inst<__bf16, BMV, MMISS_EPI_LNFOLD_BF16>(st, A, W, ep, M, N, K)                   \
+                   : launch_gemm_inst<__bf16, BMV, MMISS_EPI_LNFOLD_QGELU_BF16>(st, A, W, ep, M, N, K);
+    if (epi != MMISS_EPI_LNFOLD_BF16 && epi != MMISS_EPI_LNFOLD_QGELU_BF16) MM_FAIL(MMISS_ERR_ARG, "gemm_fold: epilogue %d", epi);
+    switch (bm) {
+        GEMM_FOLD_CASE(128)
+        GEMM_FOLD_CASE(160)
+        GEMM_FOLD_CASE(192)
+    }
+#undef GEMM_FOLD_CASE
+    MM_FAIL(MMISS_ERR_ARG, "gemm_fold: unsupported tile height %d", bm);
 }
 
 // LayerNorm-fused bf16 GEMM: X f32 [M,K] (the residual stream), ep.ln_* set; epilogues BIAS_BF16 / BIAS_QGELU_BF16.
