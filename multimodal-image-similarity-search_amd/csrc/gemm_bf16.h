@@ -66,6 +66,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + (bid >> 3);
 }
 
+// Logical tile id -> (bm, bn). mode 0: n fastest (blocks sharing an A panel adjacent); 1: m fastest; g >= 2: grouped,
+// bands of g m-tiles, m fastest inside a band, so that the ~64 tiles an XCD runs at once cover about g x (64/g)
+// tiles and touch g A panels + 64/g W panels instead of ~3 + nbn (less L2 working set per wave of tiles).
+__device__ __forceinline__ void tile_order(int wg, int nbm, int nbn, int mode, int& bm, int& bn) {
+    if (mode == 0) { bm = wg / nbn; bn = wg - bm * nbn; }
+    else if (mode == 1) { bn = wg / nbm; bm = wg - bn * nbm; }
+    else {
+        const int per = mode * nbn;
+        const int grp = wg / per, first = grp * mode;
+        const int gsz = min(mode, nbm - first);
+        const int in = wg - grp * per;
+        bn = in / gsz; bm = first + (in - bn * gsz);
+    }
+}
+
 // GROUPMAX group g <-> rows: g = ((bn*2 + wn)*4 + fg); member e (0..15) is row
 //   bn*128 + wn*64 + 4*fg + (e >> 2)*16 + (e & 3)
 __host__ __device__ __forceinline__ int64_t groupmax_row(int64_t g, int e) {
@@ -239,8 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
     const int nwg = nbm * nbn;
     const int wg = xcd_remap(blockIdx.x, nwg);
     int bm, bn;
-    if (ep.m_fast) { bn = wg / nbm; bm = wg - bn * nbm; }
-    else           { bm = wg / nbn; bn = wg - bm * nbn; }
+    tile_order(wg, nbm, nbn, ep.m_fast, bm, bn);
 
     const IN* Ab = A + (size_t)bm * BM * K;
     const IN* Wb = W + (size_t)bn * GEMM_BN * K;
@@ -427,8 +441,11 @@ static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const 
         attr_done = true;
     }
     const int nwg = (M / BM) * (N / GEMM_BN);
+    GemmEpi e2 = ep;
+    const int forced = mmiss_option("gemm_group_m", -1);  // experiment knob (tools/gemm_order_sweep.py)
+    if (forced >= 0 && e2.m_fast != 1) e2.m_fast = forced;
     hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN>), dim3(nwg), dim3(256), LDS, st, reinterpret_cast<const IN*>(A),
-                       reinterpret_cast<const IN*>(W), M, N, K, ep);
+                       reinterpret_cast<const IN*>(W), M, N, K, e2);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }

@@ -34,8 +34,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ 
     const int nwg = nbm * nbn;
     const int wg = xcd_remap(blockIdx.x, nwg);
     int bm, bn;
-    if (ep.m_fast) { bn = wg / nbm; bm = wg - bn * nbm; }
-    else           { bm = wg / nbn; bn = wg - bm * nbn; }
+    tile_order(wg, nbm, nbn, ep.m_fast, bm, bn);
     const IN* Ab = A + (size_t)bm * 256 * K;
     const IN* Wb = W + (size_t)bn * 256 * K;
     const int nt = K / GEMM_BK;

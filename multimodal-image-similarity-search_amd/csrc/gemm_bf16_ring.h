@@ -47,8 +47,7 @@ __global__ __launch_bounds__(256, 2) void gemm16r_kernel(const IN* __restrict__ 
     const int nwg = nbm * nbn;
     const int wg = xcd_remap(blockIdx.x, nwg);
     int bm, bn;
-    if (ep.m_fast) { bn = wg / nbm; bm = wg - bn * nbm; }
-    else           { bm = wg / nbn; bn = wg - bm * nbn; }
+    tile_order(wg, nbm, nbn, ep.m_fast, bm, bn);
     const IN* Ab = A + (size_t)bm * BM * K;
     const IN* Wb = W + (size_t)bn * GEMM_BN * K;
     const int nst = K / GR_BK;

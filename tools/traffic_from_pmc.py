@@ -1,0 +1,69 @@
+"""Aggregate two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; each collected in its OWN run with --kernel-trace only)
+into profiles/rNN_traffic.json: average HBM bytes per launch of the kernel classes bench.py's roofline reports.
+
+    python tools/traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> profiles/r01_traffic.json
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB-like
+units of 1024 B... the guide's gfx950 note: FETCH_SIZE under-reports by 2x (64 B requests counted as 32 B), so fetch
+bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE * 1024 is taken as is. Cross-check: the flat scan of a 10M x 512 f16 index
+reads 10.24 GB algorithmically and the corrected counter says 10.24 GB.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+# library kernel class -> regex over the (mangled or demangled) kernel name
+CLASSES = {
+    "gemm_bf16_bias_resid": r"gemm16_kernelIDF16bLi160ELi3E",
+    "gemm_bf16_bias_resid_pruned": r"gemm16_kernelIDF16bLi128ELi3E",
+    "gemm_bf16_bias_qgelu": r"gemm16_kernelIDF16bLi192ELi2E",
+    "gemm_bf16_bias": r"gemm16_kernelIDF16bLi192ELi1E",
+    "gemm_bf16_patch": r"gemm16_kernelIDF16bLi160ELi4E",
+    "score_gemm_f16": r"gemm256_kernelIDF16_Li5E",
+    "scan_topk_f16": r"scan_topk_kernelIDF16_",
+    "layernorm": r"layernorm_kernel<true>",
+    "attention": r"attention_kernel<",
+    "im2col": r"im2col_kernel<",
+}
+ALGORITHMIC = {  # bytes per launch the kernel must move, averaged over the shapes in the class
+    "gemm_bf16_bias_resid": 130.7e6, "gemm_bf16_bias_qgelu": 103.0e6, "gemm_bf16_bias": 82.2e6,
+    "scan_topk_f16": 10.24e9,
+}
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main(fetch_csv, write_csv, out):
+    fetch, write = per_kernel(fetch_csv), per_kernel(write_csv)
+    res = {"_note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, "
+                    "--kernel-trace only), FETCH_SIZE doubled as MI355X_MICROARCH.md 'HBM' prescribes for gfx950; command: "
+                    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 2 "
+                    "--no-cpu-baseline --no-kernel-events --no-text; aggregated by tools/traffic_from_pmc.py"}
+    for cls, pat in CLASSES.items():
+        rx = re.compile(pat)
+        fv = [v for k, vs in fetch.items() if rx.search(k) for v in vs]
+        wv = [v for k, vs in write.items() if rx.search(k) for v in vs]
+        if not fv or not wv:
+            continue
+        fb = 2.0 * 1024.0 * sum(fv) / len(fv)
+        wb = 1024.0 * sum(wv) / len(wv)
+        ent = {"symbol_regex": pat, "launches_sampled": len(fv), "fetch_bytes_corrected": round(fb),
+               "write_bytes": round(wb), "traffic_bytes": round(fb + wb)}
+        if cls in ALGORITHMIC:
+            ent["algorithmic_bytes_avg"] = ALGORITHMIC[cls]
+        res[cls] = ent
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
