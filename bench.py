@@ -270,6 +270,42 @@ def main():
                    "image_encode_plus_top10_ms_host_buffers": round(host_ms, 3), "batch": 1,
                    "note": "the reference runs batch 1 on the CPU (backend/app/utils.py:76-77)"}
 
+    # ---------------------------------------------------------------- ingest: raw RGB uploads -> embeddings
+    ingest = None
+    if rank == 0 and not args.no_text:
+        IH, IW = 480, 640
+        raw = torch.randint(0, 256, (B, IH, IW, 3), dtype=torch.uint8, device=dev)
+        offs = np.arange(B, dtype=np.int64) * (IH * IW * 3)
+        hs, ws = np.full(B, IH, np.int32), np.full(B, IW, np.int32)
+        iemb = torch.empty(B, D, device=dev)
+        for _ in range(3):
+            enc.encode_image_rgb_packed(raw, offs, hs, ws, out=iemb)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            enc.encode_image_rgb_packed(raw, offs, hs, ws, out=iemb)
+        fence()
+        idt = (time.perf_counter() - t0) / 10
+        _lib.prof_filter(None, 1)
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        for _ in range(5):
+            enc.encode_image_rgb_packed(raw, offs, hs, ws, out=iemb)
+        fence()
+        rz = {k["kernel"]: k["ms"] / k["launches"] for k in _lib.prof_read() if k["kernel"].startswith("resize")}
+        _lib.prof_enable(False)
+        raw_host = raw.cpu().numpy().reshape(-1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            enc.encode_image_rgb_packed(raw_host, offs, hs, ws)
+        hdt = (time.perf_counter() - t0) / 3
+        rz_ms = rz.get("resize_crop", 0.0)
+        ingest = {"images_per_s_device_resident": round(B / idt, 1), "images_per_s_host_buffers": round(B / hdt, 1),
+                  "batch": B, "source": f"{IW}x{IH} RGB8", "resize_crop_kernel_ms": round(rz_ms, 4),
+                  "resize_coeffs_kernel_ms": round(rz.get("resize_coeffs", 0.0), 4),
+                  "resize_crop_gbs": round((B * IH * IW * 3 + B * 224 * 224 * 3) / (rz_ms * 1e-3) / 1e9, 1) if rz_ms else None,
+                  "note": "resize(shortest edge 224, bicubic, Pillow-exact) + centre crop + rescale + normalise + ViT-B/32"}
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -290,7 +326,7 @@ def main():
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),
-            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -112,6 +112,23 @@ int mmiss_encode_image(mmiss_encoder* enc, const float* pixels, int32_t B, float
 int mmiss_encode_image_u8(mmiss_encoder* enc, const uint8_t* pixels_u8, int32_t B, float* out);
 
 /*
+ * Raw decoded images of ANY size (what PIL hands the processor at backend/app/utils.py:76): B tightly packed RGB8
+ * images (row stride 3*W, no padding) laid end to end in `rgb` (host or device, rgb_bytes long); image b starts at
+ * byte offsets[b] and is heights[b] x widths[b] (host arrays). The library does the CLIPImageProcessor geometry on
+ * the GPU — resize so the shortest edge is S = v_image with PIL's bicubic filter (long edge int(S*long/short)),
+ * centre crop S x S (HF:image_processing_clip.py:23-34) — bit-identical to Pillow's 8-bit Image.resize, then
+ * rescale/normalise/encode as mmiss_encode_image_u8. JPEG/PNG decoding and convert("RGB") stay with the caller.
+ *   mmiss_resize_crop_rgb   out_u8: uint8 [B,S,S,3] (host or device) — the crops themselves;
+ *   mmiss_encode_image_rgb  out: float32 [B,proj_dim] unit rows.
+ * Errors: sizes outside 1..65536, bytes outside the blob -> MMISS_ERR_ARG; a downscale needing more than 4096 filter
+ * taps per output pixel -> MMISS_ERR_UNSUPPORTED.
+ */
+int mmiss_resize_crop_rgb(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_bytes, const int64_t* offsets,
+                          const int32_t* heights, const int32_t* widths, int32_t B, uint8_t* out_u8);
+int mmiss_encode_image_rgb(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_bytes, const int64_t* offsets,
+                           const int32_t* heights, const int32_t* widths, int32_t B, float* out);
+
+/*
  * ids: int32 [B,T], T <= t_ctx, rows = BOS ... EOS then padding (CLIPTokenizer output,
  *      backend/app/utils.py:88). out: float32 [B,proj_dim], rows unit-norm. The pooled row is the
  *      first EOS position, so the padding mask cannot change the result (causal attention).

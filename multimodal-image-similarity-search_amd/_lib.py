@@ -59,6 +59,8 @@ SIGNATURES = {
     "mmiss_encoder_set_stream": (_I, [_P, _P, _I32]),
     "mmiss_encode_image": (_I, [_P, _P, _I32, _P]),
     "mmiss_encode_image_u8": (_I, [_P, _P, _I32, _P]),
+    "mmiss_resize_crop_rgb": (_I, [_P, _P, _I64, _P, _P, _P, _I32, _P]),
+    "mmiss_encode_image_rgb": (_I, [_P, _P, _I64, _P, _P, _P, _I32, _P]),
     "mmiss_encode_text": (_I, [_P, _P, _I32, _I32, _P]),
     "mmiss_encoder_tap": (_I, [_P, _I, _I, _P, _I64, C.POINTER(_I64)]),
     "mmiss_index_create": (_I, [_I32, _I32, _I, _I64, C.POINTER(_P)]),

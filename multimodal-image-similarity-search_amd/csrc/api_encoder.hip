@@ -5,6 +5,7 @@
 #include "gemm_bf16_256.h"
 #include "gemm_bf16_ring.h"
 #include "encoder_kernels.h"
+#include "preprocess_kernels.h"
 #include <map>
 #include <set>
 
@@ -95,6 +96,11 @@ struct mmiss_encoder {
     DevBuf pre_g, pre_b;
     DevBuf patches;   // bf16 [Mpp, Kp]
     DevBuf pix_stage; // host->device staging of pixels
+    // raw-RGB input (N2): source blob staging, per-image descriptors, fixed-point taps, windows, uint8 crops
+    DevBuf raw_stage, rz_desc, rz_pool, rz_bounds, crop_stage;
+    ResizeDesc* rz_host = nullptr;   // pinned; rz_copied marks the end of its last host->device copy
+    size_t rz_host_cap = 0;
+    hipEvent_t rz_copied = nullptr;
     // text-only
     DevBuf tok;       // f32 [vocab, t_hidden]
     DevBuf ids_stage;
@@ -355,6 +361,68 @@ int finish_call(mmiss_encoder* e, hipStream_t st, bool must_sync) {
     return MMISS_OK;
 }
 
+
+// Resize + centre-crop images b0 .. b0+nb-1 of a raw RGB8 blob into dst_dev (uint8 [nb,S,S,3], device), on st.
+int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb_bytes, const int64_t* offsets,
+                 const int32_t* heights, const int32_t* widths, int b0, int nb, uint8_t* dst_dev, hipStream_t st) {
+    const int S = e->cfg.v_image;
+    if (!e->rz_copied) MM_HIP(hipEventCreateWithFlags(&e->rz_copied, hipEventDisableTiming));
+    else MM_HIP(hipEventSynchronize(e->rz_copied));  // the previous call's descriptor upload has left the buffer
+    if ((size_t)nb > e->rz_host_cap) {
+        if (e->rz_host) (void)hipHostFree(e->rz_host);
+        e->rz_host = nullptr; e->rz_host_cap = 0;
+        MM_HIP(hipHostMalloc(reinterpret_cast<void**>(&e->rz_host), sizeof(ResizeDesc) * (size_t)nb, hipHostMallocDefault));
+        e->rz_host_cap = (size_t)nb;
+    }
+    int64_t pool = 0, lo = INT64_MAX, hi = 0;
+    for (int i = 0; i < nb; ++i) {
+        const int H = heights[b0 + i], W = widths[b0 + i];
+        const int64_t off = offsets[b0 + i];
+        if (H < 1 || W < 1 || H > (1 << 16) || W > (1 << 16))
+            MM_FAIL(MMISS_ERR_ARG, "image %d: size %d x %d outside 1..65536", b0 + i, W, H);
+        const int64_t bytes = (int64_t)H * W * 3;
+        if (off < 0 || off + bytes > rgb_bytes)
+            MM_FAIL(MMISS_ERR_ARG, "image %d: bytes [%lld, %lld) outside the %lld-byte source", b0 + i, (long long)off,
+                    (long long)(off + bytes), (long long)rgb_bytes);
+        ResizeDesc& d = e->rz_host[i];
+        resize_geometry(H, W, S, d);
+        if (d.ksx > 4096 || d.ksy > 4096)
+            MM_FAIL(MMISS_ERR_UNSUPPORTED, "image %d: %d x %d -> %d needs %d / %d filter taps (limit 4096)", b0 + i, W, H, S,
+                    d.ksx, d.ksy);
+        d.src_off = off;
+        d.kx_off = pool; pool += (int64_t)d.ksx * S;
+        d.ky_off = pool; pool += (int64_t)d.ksy * S;
+        lo = off < lo ? off : lo;
+        hi = off + bytes > hi ? off + bytes : hi;
+    }
+    const uint8_t* src = rgb;
+    if (!rgb_dev) {  // stage the byte range this chunk touches
+        MM_TRY(e->raw_stage.ensure((size_t)(hi - lo)));
+        MM_HIP(hipMemcpyAsync(e->raw_stage.p, rgb + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+        for (int i = 0; i < nb; ++i) e->rz_host[i].src_off -= lo;
+        src = e->raw_stage.as<uint8_t>();
+    }
+    MM_TRY(e->rz_desc.ensure(sizeof(ResizeDesc) * (size_t)nb));
+    MM_TRY(e->rz_pool.ensure((size_t)pool * 4));
+    MM_TRY(e->rz_bounds.ensure((size_t)nb * 4 * S * 4));
+    MM_HIP(hipMemcpyAsync(e->rz_desc.p, e->rz_host, sizeof(ResizeDesc) * (size_t)nb, hipMemcpyHostToDevice, st));
+    MM_HIP(hipEventRecord(e->rz_copied, st));
+    {
+        MM_PROF("resize_coeffs", st, 0.0, (double)pool * 4);
+        hipLaunchKernelGGL(resize_coeffs_kernel, dim3(nb, 2), dim3(256), 0, st, e->rz_desc.as<ResizeDesc>(),
+                           e->rz_pool.as<int32_t>(), e->rz_bounds.as<int32_t>(), S);
+        MM_HIP(hipGetLastError());
+    }
+    {
+        MM_PROF("resize_crop", st, 0.0, (double)(hi - lo) + (double)nb * S * S * 3);
+        hipLaunchKernelGGL(resize_crop_kernel, dim3((S + MMISS_RESIZE_ROWS - 1) / MMISS_RESIZE_ROWS, (3 * S + 255) / 256, nb),
+                           dim3(256), 0, st, src, e->rz_desc.as<ResizeDesc>(), e->rz_pool.as<int32_t>(),
+                           e->rz_bounds.as<int32_t>(), dst_dev, S);
+        MM_HIP(hipGetLastError());
+    }
+    return MMISS_OK;
+}
+
 }  // namespace
 
 // ================================================================================================ C-ABI
@@ -434,6 +502,8 @@ extern "C" int mmiss_encoder_destroy(mmiss_encoder* enc) {
     (void)hipSetDevice(enc->device);
     (void)hipDeviceSynchronize();
     if (enc->own_stream) (void)hipStreamDestroy(enc->own_stream);
+    if (enc->rz_copied) (void)hipEventDestroy(enc->rz_copied);
+    if (enc->rz_host) (void)hipHostFree(enc->rz_host);
     delete enc;
     return MMISS_OK;
 }
@@ -567,6 +637,57 @@ extern "C" int mmiss_encode_image(mmiss_encoder* enc, const float* pixels, int32
 
 extern "C" int mmiss_encode_image_u8(mmiss_encoder* enc, const uint8_t* pixels_u8, int32_t B, float* out) {
     return encode_image_impl(enc, pixels_u8, true, B, out);
+}
+
+// raw RGB8 images of any size: resize (shortest edge, bicubic) + centre crop on the GPU, then the uint8 encode path
+static int encode_rgb_impl(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_bytes, const int64_t* offsets,
+                           const int32_t* heights, const int32_t* widths, int32_t B, uint8_t* out_u8, float* out_emb) {
+    if (!enc || !rgb || !offsets || !heights || !widths || (!out_u8 && !out_emb))
+        MM_FAIL(MMISS_ERR_ARG, "mmiss_*_rgb: null argument");
+    if (B < 0 || rgb_bytes < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_*_rgb: B = %d, rgb_bytes = %lld", B, (long long)rgb_bytes);
+    std::lock_guard<std::mutex> lk(enc->mu);
+    if (out_emb && !enc->finalized) MM_FAIL(MMISS_ERR_STATE, "mmiss_encode_image_rgb before mmiss_encoder_finalize");
+    if (B == 0) return MMISS_OK;
+    MM_TRY(mmiss_use_device(enc->device));
+    hipStream_t st = enc->stream();
+    const int maxb = enc->cfg.max_batch_image, S = enc->cfg.v_image, P = enc->cfg.proj_dim;
+    if (out_emb) {
+        MM_TRY(ensure_tower_ws(enc, enc->vis, maxb, P));
+        if (!enc->patches.p) {
+            const int64_t Mpp = round_up((int64_t)maxb * enc->G * enc->G, 128) + 192;
+            MM_TRY(alloc_zero(enc->patches, (size_t)Mpp * enc->Kp * 2));
+        }
+    }
+    const bool in_dev = mmiss_is_device_ptr(rgb);
+    const bool out_dev = mmiss_is_device_ptr(out_emb ? (const void*)out_emb : (const void*)out_u8);
+    const size_t crop_bytes = (size_t)3 * S * S;
+    MM_TRY(enc->crop_stage.ensure(crop_bytes * maxb));
+    for (int b0 = 0; b0 < B; b0 += maxb) {
+        const int nb = (B - b0 < maxb) ? B - b0 : maxb;
+        uint8_t* crops = (out_u8 && out_dev) ? out_u8 + crop_bytes * b0 : enc->crop_stage.as<uint8_t>();
+        MM_TRY(resize_chunk(enc, rgb, in_dev, rgb_bytes, offsets, heights, widths, b0, nb, crops, st));
+        if (out_u8 && !out_dev) {
+            MM_HIP(hipMemcpyAsync(out_u8 + crop_bytes * b0, crops, crop_bytes * nb, hipMemcpyDeviceToHost, st));
+        }
+        if (out_emb) {
+            float* dst = out_dev ? out_emb + (size_t)b0 * P : enc->vis.out_stage.as<float>();
+            MM_TRY(encode_image_chunk(enc, crops, true, nb, dst, st));
+            if (!out_dev) MM_HIP(hipMemcpyAsync(out_emb + (size_t)b0 * P, dst, (size_t)nb * P * 4, hipMemcpyDeviceToHost, st));
+        }
+        // staging buffers (source bytes, descriptors, crops, output) are reused by the next chunk
+        if (b0 + maxb < B || !out_dev || !in_dev) MM_HIP(hipStreamSynchronize(st));
+    }
+    return finish_call(enc, st, !out_dev);
+}
+
+extern "C" int mmiss_resize_crop_rgb(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_bytes, const int64_t* offsets,
+                                     const int32_t* heights, const int32_t* widths, int32_t B, uint8_t* out_u8) {
+    return encode_rgb_impl(enc, rgb, rgb_bytes, offsets, heights, widths, B, out_u8, nullptr);
+}
+
+extern "C" int mmiss_encode_image_rgb(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_bytes, const int64_t* offsets,
+                                      const int32_t* heights, const int32_t* widths, int32_t B, float* out) {
+    return encode_rgb_impl(enc, rgb, rgb_bytes, offsets, heights, widths, B, nullptr, out);
 }
 
 extern "C" int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t B, int32_t T, float* out) {

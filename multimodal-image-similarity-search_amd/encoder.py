@@ -197,6 +197,65 @@ class ClipEncoder:
         _lib.check(fn(self._h, _lib.ptr(pixels), B, _lib.ptr(out)))
         return out
 
+    @staticmethod
+    def _pack_rgb(images):
+        """Sequence of uint8 [H,W,3] arrays -> (blob uint8 [sum H*W*3], offsets i64 [B], heights i32 [B], widths i32 [B])."""
+        arrs = []
+        for im in images:
+            a = np.ascontiguousarray(im, dtype=np.uint8)
+            if a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
+                raise ValueError(f"raw images must be uint8 [H,W,3], got {a.shape}")
+            arrs.append(a)
+        sizes = np.array([a.size for a in arrs], dtype=np.int64)
+        offsets = np.zeros(len(arrs), dtype=np.int64)
+        if len(arrs) > 1:
+            offsets[1:] = np.cumsum(sizes)[:-1]
+        blob = np.concatenate([a.reshape(-1) for a in arrs]) if arrs else np.zeros(0, np.uint8)
+        heights = np.array([a.shape[0] for a in arrs], dtype=np.int32)
+        widths = np.array([a.shape[1] for a in arrs], dtype=np.int32)
+        return blob, offsets, heights, widths
+
+    def resize_crop_rgb(self, images) -> np.ndarray:
+        """Raw decoded RGB images of any size -> uint8 [B,S,S,3]: CLIPImageProcessor's resize (shortest edge, bicubic)
+        + centre crop (HF:image_processing_clip.py:23-34) on the GPU, bit-identical to Pillow."""
+        blob, off, hs, ws = self._pack_rgb(images)
+        B, S = len(off), self.shape.v_image
+        out = np.empty((B, S, S, 3), dtype=np.uint8)
+        if B == 0:
+            return out
+        self._sync_stream(blob)
+        _lib.check(self._lib.mmiss_resize_crop_rgb(self._h, _lib.ptr(blob), blob.size, _lib.ptr(off), _lib.ptr(hs),
+                                                   _lib.ptr(ws), B, _lib.ptr(out)))
+        return out
+
+    def encode_image_rgb(self, images, out=None) -> np.ndarray:
+        """Raw decoded RGB images of any size (uint8 [H,W,3] each) -> float32 [B,proj] unit rows; resize, crop,
+        rescale, normalise and the tower all run on the GPU (backend/app/utils.py:76-78 for a batch)."""
+        return self.encode_image_rgb_packed(*self._pack_rgb(images), out=out)
+
+    def encode_image_rgb_packed(self, blob, offsets, heights, widths, out=None):
+        """The packed form of encode_image_rgb: blob = uint8 bytes of all images end to end (numpy, or a torch tensor
+        on this GPU — then the result is a torch tensor too), image b at offsets[b], heights[b] x widths[b]."""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        hs = np.ascontiguousarray(heights, dtype=np.int32)
+        ws = np.ascontiguousarray(widths, dtype=np.int32)
+        B = len(off)
+        if len(hs) != B or len(ws) != B:
+            raise ValueError("offsets, heights and widths must have one entry per image")
+        if not _is_torch(blob):
+            blob = np.ascontiguousarray(blob, dtype=np.uint8).reshape(-1)
+        elif str(blob.dtype) != "torch.uint8":
+            raise ValueError("blob must be uint8")
+        else:
+            blob = blob.contiguous().view(-1)
+        out = self._out(blob, B) if out is None else out
+        if B == 0:
+            return out
+        self._sync_stream(blob)
+        _lib.check(self._lib.mmiss_encode_image_rgb(self._h, _lib.ptr(blob), int(blob.numel() if _is_torch(blob) else blob.size),
+                                                    _lib.ptr(off), _lib.ptr(hs), _lib.ptr(ws), B, _lib.ptr(out)))
+        return out
+
     def encode_text(self, input_ids, out=None, trim_padding: bool = True):
         """input_ids: int [B,T] (T <= context length), rows = BOS ... EOS, padding -> float32 [B,proj] unit rows.
 

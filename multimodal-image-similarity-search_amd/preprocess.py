@@ -138,6 +138,17 @@ class ClipProcessor:
         tok = ClipBPETokenizer.from_files(vocab, merges) if os.path.exists(vocab) and os.path.exists(merges) else None
         return cls(shape, tok, max_length)
 
+    @staticmethod
+    def rgb_arrays(images: Sequence) -> list:
+        """PIL images (or uint8 arrays) -> list of uint8 [H,W,3] arrays: `convert("RGB")`, the only host step left
+        before ClipEncoder.encode_image_rgb (do_convert_rgb of the HF processor)."""
+        out = []
+        for im in images:
+            if hasattr(im, "convert"):
+                im = im.convert("RGB")
+            out.append(np.asarray(im, dtype=np.uint8))
+        return out
+
     def crop_images_u8(self, images: Sequence) -> np.ndarray:
         """-> uint8 [B,S,S,3]; the GPU applies x/255 and (x-mean)/std inside the patchify kernel."""
         return np.stack([np.asarray(_resize_crop(im, self.image_size), dtype=np.uint8) for im in images])

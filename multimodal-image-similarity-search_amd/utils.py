@@ -96,8 +96,9 @@ def generate_clip_embedding(image=None, text: Optional[str] = None, model=None, 
     result = {}
     if image is not None:
         start_time = time.time()
-        pixels = processor.preprocess_images([image])            # processor(images=image, return_tensors="pt")
-        result["image"] = np.asarray(model.encode_image(pixels))  # get_image_features + / norm  -> f32 [1, D]
+        # processor(images=image) + get_image_features + "/ norm" -> f32 [1, D]: the processor's resize / crop /
+        # rescale / normalise run on the GPU in front of the tower; only convert("RGB") stays on the host
+        result["image"] = np.asarray(model.encode_image_rgb(processor.rgb_arrays([image])))
         logger.info(f"Image embedding generated in {time.time() - start_time:.2f} seconds")
     if text is not None:
         start_time = time.time()
@@ -115,7 +116,7 @@ def generate_clip_embeddings(images: Optional[Sequence] = None, texts: Optional[
         model, processor = load_clip_model()
     result = {}
     if images is not None:
-        result["image"] = np.asarray(model.encode_image(processor.preprocess_images(list(images))))
+        result["image"] = np.asarray(model.encode_image_rgb(processor.rgb_arrays(list(images))))
     if texts is not None:
         result["text"] = np.asarray(model.encode_text(processor.tokenize(list(texts))))
     elif input_ids is not None:

@@ -71,5 +71,11 @@ class OracleEncoder:
             px = co.normalize_u8(px)
         return co.embed_images(px, self.W, self.shape)
 
+    def encode_image_rgb(self, images, out=None):
+        from oracle import resize_oracle as ro
+
+        crops = np.stack([ro.resize_crop_u8(np.asarray(im, dtype=np.uint8), self.shape.v_image) for im in images])
+        return self.encode_image(crops)
+
     def encode_text(self, ids, out=None):
         return co.embed_texts(np.asarray(ids), self.W, self.shape)

@@ -21,6 +21,9 @@ class _Proc:
     def preprocess_images(self, images):
         return np.stack([co.preprocess_image(im, self.shape.v_image) for im in images])
 
+    def rgb_arrays(self, images):
+        return [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images]
+
     def tokenize(self, texts):
         s = self.shape
         return np.stack([co.synthetic_text_ids(1, s.t_ctx, s.t_vocab, s.eos_token_id, seed=sum(map(ord, t)) % 9973)[0] for t in texts])

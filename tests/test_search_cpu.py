@@ -12,7 +12,12 @@ class _Proc:
         self.shape = shape
 
     def preprocess_images(self, images):
-        return np.stack([np.asarray(im, np.float32) for im in images])
+        from oracle import resize_oracle as ro
+
+        return co.normalize_u8(np.stack([ro.resize_crop_u8(np.asarray(im, np.uint8), self.shape.v_image) for im in images]))
+
+    def rgb_arrays(self, images):
+        return [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in images]
 
     def tokenize(self, texts):
         return np.stack([co.synthetic_text_ids(1, self.shape.t_ctx, self.shape.t_vocab, self.shape.eos_token_id, seed=len(t))[0] for t in texts])
@@ -37,8 +42,8 @@ def env(monkeypatch):
 
 
 def _img(seed):
-    s = co.TINY
-    return np.random.Generator(np.random.Philox(seed)).standard_normal((3, s.v_image, s.v_image), dtype=np.float32)
+    """A raw decoded RGB image (uint8 [H,W,3]) of an odd size, as PIL would hand it to the processor."""
+    return np.random.Generator(np.random.Philox(seed)).integers(0, 256, (40 + seed, 57, 3), dtype=np.uint8)
 
 
 def test_generate_clip_embedding_shapes_and_norms(env):
