@@ -375,6 +375,7 @@ int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb
         e->rz_host_cap = (size_t)nb;
     }
     int64_t pool = 0, lo = INT64_MAX, hi = 0;
+    int max_ksx = 0;
     for (int i = 0; i < nb; ++i) {
         const int H = heights[b0 + i], W = widths[b0 + i];
         const int64_t off = offsets[b0 + i];
@@ -390,6 +391,7 @@ int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb
             MM_FAIL(MMISS_ERR_UNSUPPORTED, "image %d: %d x %d -> %d needs %d / %d filter taps (limit 4096)", b0 + i, W, H, S,
                     d.ksx, d.ksy);
         d.src_off = off;
+        max_ksx = d.ksx > max_ksx ? d.ksx : max_ksx;
         d.kx_off = pool; pool += (int64_t)d.ksx * S;
         d.ky_off = pool; pool += (int64_t)d.ksy * S;
         lo = off < lo ? off : lo;
@@ -415,9 +417,8 @@ int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb
     }
     {
         MM_PROF("resize_crop", st, 0.0, (double)(hi - lo) + (double)nb * S * S * 3);
-        hipLaunchKernelGGL(resize_crop_kernel, dim3((S + MMISS_RESIZE_ROWS - 1) / MMISS_RESIZE_ROWS, (3 * S + 255) / 256, nb),
-                           dim3(256), 0, st, src, e->rz_desc.as<ResizeDesc>(), e->rz_pool.as<int32_t>(),
-                           e->rz_bounds.as<int32_t>(), dst_dev, S);
+        launch_resize_crop(st, max_ksx, src, rgb_dev ? rgb_bytes : hi - lo, e->rz_desc.as<ResizeDesc>(), e->rz_pool.as<int32_t>(),
+                           e->rz_bounds.as<int32_t>(), dst_dev, S, nb);
         MM_HIP(hipGetLastError());
     }
     return MMISS_OK;

@@ -12,10 +12,10 @@
 // Two kernels:
 //   resize_coeffs_kernel   one thread per (image, axis, output index inside the crop window): the fixed-point taps,
 //                          computed on the device in double with contraction off (same operation order as Pillow);
-//   resize_crop_kernel     one block per (16 output rows, 256 of the 3*S (column, channel) values, image): streams
-//                          the source rows its rows need; a thread computes the horizontally resampled uint8 value
-//                          of its (column, channel) for the row and feeds it to the <=16 vertical accumulators it
-//                          owns, so the intermediate image never exists in memory. Only the crop window is computed.
+//   resize_crop_kernel     one block per (16 output rows, 256 output columns, image): streams the source rows its
+//                          rows need; a thread computes the horizontally resampled uint8 RGB of its column for the
+//                          row and feeds it to the 16 x 3 vertical accumulators it owns, so the intermediate image
+//                          never exists in memory. Only the crop window is computed.
 // Integer work bound by byte loads of the source (each source row is read once per 16-row tile it contributes to);
 // at the sizes of the reference's uploads (<= a few MP) the whole batch costs a fraction of one encoder layer.
 #pragma once
@@ -86,55 +86,152 @@ __device__ __forceinline__ int clip8_fixed(int32_t v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// grid (ceil(S/16), ceil(3S/256), B), block 256. dst: uint8 [B,S,S,3].
-__global__ __launch_bounds__(256) void resize_crop_kernel(const uint8_t* __restrict__ src,
+// grid (ceil(S/16), ceil(S/256), B), block 256: a thread owns one output COLUMN (3 channels) of the tile's 16 rows.
+// The kernel is bound by load latency and load-instruction count, not bandwidth, so:
+//   * KMAX > 0 (every image of the launch has ksx <= KMAX): the column's taps live in registers, the tap loop is fully
+//     unrolled and each tap is ONE unaligned 4-byte load holding R,G,B (scalar row base + 32-bit per-thread offset;
+//     the last row of an image that ends the blob uses byte loads, so nothing is read past the blob); two source rows
+//     per trip keep 2*KMAX loads in flight. Taps past xcnt re-read the last valid pixel with weight 0. Needs images
+//     under 2 GiB (32-bit in-row offsets are always enough; the row base is 64-bit).
+//   * KMAX == 0: generic (any ksx): taps streamed from the pool, three byte loads per tap.
+//   * the vertical taps of the tile are expanded once per 64 source rows into a dense LDS table kyt[row][16]
+//     (zero outside a row's window), so the vertical pass is 4 ds_read_b128 + 48 MADs per source row, no branches.
+#define MMISS_RESIZE_CHUNK 64
+template <int KMAX>
+__global__ __launch_bounds__(256) void resize_crop_kernel(const uint8_t* __restrict__ src, int64_t blob_bytes,
                                                           const ResizeDesc* __restrict__ desc,
                                                           const int32_t* __restrict__ pool,
                                                           const int32_t* __restrict__ bounds,
                                                           uint8_t* __restrict__ dst, int S) {
-    constexpr int RT = MMISS_RESIZE_ROWS;
+    constexpr int RT = MMISS_RESIZE_ROWS, CH = MMISS_RESIZE_CHUNK;
     constexpr int32_t HALF = 1 << (MMISS_RESIZE_PRECISION_BITS - 1);
+    __shared__ __attribute__((aligned(16))) int32_t kyt[CH][RT];
     const int b = blockIdx.z;
     const ResizeDesc d = desc[b];
     const int r0 = blockIdx.x * RT;
-    const int v = blockIdx.y * 256 + threadIdx.x;  // (column, channel) value of the output row
-    const bool live = v < 3 * S;
-    const int col = live ? v / 3 : 0, ch = live ? v - col * 3 : 0;
+    const int col_raw = blockIdx.y * 256 + threadIdx.x;
+    const bool live = col_raw < S;
+    const int col = live ? col_raw : 0;
     const int32_t* bnd = bounds + (size_t)b * 4 * S;
-    const int xmin = bnd[col], xcnt = live ? bnd[S + col] : 0;
-    // vertical windows of this tile's rows (block-uniform)
-    int ymin[RT], ycnt[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const bool ok = r0 + r < S;
-        ymin[r] = ok ? bnd[2 * S + r0 + r] : 0;
-        ycnt[r] = ok ? bnd[3 * S + r0 + r] : 0;
-    }
+    const int xmin = bnd[col], xcnt = bnd[S + col];
     const int rl = (r0 + RT < S ? r0 + RT : S) - 1;
-    const int y0 = ymin[0], y1 = bnd[2 * S + rl] + bnd[3 * S + rl];
+    const int y0 = bnd[2 * S + r0], y1 = bnd[2 * S + rl] + bnd[3 * S + rl];
     const int32_t* kx = pool + d.kx_off + col;
-    const int32_t* ky = pool + d.ky_off + (int64_t)r0 * d.ksy;
-    const uint8_t* sp = src + d.src_off + (int64_t)xmin * 3 + ch;
+    const int32_t* ky = pool + d.ky_off;
+    const uint8_t* img = src + d.src_off;            // block-uniform
     const int64_t row_stride = (int64_t)d.W * 3;
-    int32_t acc[RT];
+    // a 4-byte load at the image's very last pixel would run one byte past the blob when the image ends the blob
+    const bool tail_risk = d.src_off + (int64_t)d.H * row_stride + 1 > blob_bytes;
+    int32_t acc[RT][3];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = HALF;
+    for (int r = 0; r < RT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = HALF;
 
-    for (int y = y0; y < y1; ++y) {
-        const uint8_t* row = sp + y * row_stride;
-        int32_t s = HALF;
-        for (int x = 0; x < xcnt; ++x) s += (int32_t)row[x * 3] * kx[(int64_t)x * S];
-        const int32_t h = clip8_fixed(s);  // the uint8 pixel of Pillow's intermediate image
+    int32_t kreg[KMAX > 0 ? KMAX : 1];
+    uint32_t off[KMAX > 0 ? KMAX : 1];  // byte offset of tap x inside a source row
+    if constexpr (KMAX > 0) {
+        const int last = (xcnt - 1) * 3;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const int t = y - ymin[r];
-            if ((unsigned)t < (unsigned)ycnt[r]) acc[r] += h * ky[r * d.ksy + t];
+        for (int x = 0; x < KMAX; ++x) {
+            kreg[x] = x < xcnt ? kx[(int64_t)x * S] : 0;
+            off[x] = (uint32_t)(xmin * 3 + (x * 3 < last ? x * 3 : last));
+        }
+    }
+
+    auto hpass = [&](int y, int32_t (&h)[3]) {
+        const uint8_t* row = img + y * row_stride;    // block-uniform: scalar base + per-thread 32-bit offsets
+        int32_t s0 = HALF, s1 = HALF, s2 = HALF;
+        if constexpr (KMAX > 0) {
+            uint32_t px[KMAX];
+            if (tail_risk && y == d.H - 1) {
+#pragma unroll
+                for (int x = 0; x < KMAX; ++x)
+                    px[x] = (uint32_t)row[off[x]] | ((uint32_t)row[off[x] + 1] << 8) | ((uint32_t)row[off[x] + 2] << 16);
+            } else {
+#pragma unroll
+                for (int x = 0; x < KMAX; ++x) __builtin_memcpy(&px[x], row + off[x], 4);
+            }
+#pragma unroll
+            for (int x = 0; x < KMAX; ++x) {
+                s0 += (int32_t)(px[x] & 0xff) * kreg[x];
+                s1 += (int32_t)((px[x] >> 8) & 0xff) * kreg[x];
+                s2 += (int32_t)((px[x] >> 16) & 0xff) * kreg[x];
+            }
+        } else {
+            const uint8_t* p = row + (int64_t)xmin * 3;
+            for (int x = 0; x < xcnt; ++x) {
+                const int32_t k = kx[(int64_t)x * S];
+                s0 += (int32_t)p[x * 3] * k;
+                s1 += (int32_t)p[x * 3 + 1] * k;
+                s2 += (int32_t)p[x * 3 + 2] * k;
+            }
+        }
+        h[0] = clip8_fixed(s0); h[1] = clip8_fixed(s1); h[2] = clip8_fixed(s2);  // Pillow's uint8 intermediate image
+    };
+    auto vpass = [&](int yy, const int32_t (&h)[3]) {
+        const int4* kr = reinterpret_cast<const int4*>(&kyt[yy][0]);
+#pragma unroll
+        for (int q = 0; q < RT / 4; ++q) {
+            const int4 k = kr[q];
+            const int32_t kk[4] = {k.x, k.y, k.z, k.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[q * 4 + e][0] += h[0] * kk[e];
+                acc[q * 4 + e][1] += h[1] * kk[e];
+                acc[q * 4 + e][2] += h[2] * kk[e];
+            }
+        }
+    };
+
+#pragma nounroll
+    for (int c0 = y0; c0 < y1; c0 += CH) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CH * RT; i += 256) {
+            const int yy = i / RT, r = i - yy * RT;
+            int32_t k = 0;
+            if (r0 + r < S) {
+                const int t = c0 + yy - bnd[2 * S + r0 + r];
+                if ((unsigned)t < (unsigned)bnd[3 * S + r0 + r]) k = ky[(int64_t)(r0 + r) * d.ksy + t];
+            }
+            kyt[yy][r] = k;
+        }
+        __syncthreads();
+        const int n = (y1 - c0 < CH) ? y1 - c0 : CH;
+        int yy = 0;
+#pragma nounroll
+        for (; yy + 1 < n; yy += 2) {
+            int32_t h0[3], h1[3];
+            hpass(c0 + yy, h0);
+            hpass(c0 + yy + 1, h1);
+            vpass(yy, h0);
+            vpass(yy + 1, h1);
+        }
+        if (yy < n) {
+            int32_t h0[3];
+            hpass(c0 + yy, h0);
+            vpass(yy, h0);
         }
     }
     if (!live) return;
 #pragma unroll
     for (int r = 0; r < RT; ++r)
-        if (r0 + r < S) dst[((int64_t)b * S + r0 + r) * S * 3 + v] = (uint8_t)clip8_fixed(acc[r]);
+        if (r0 + r < S) {
+            uint8_t* o = dst + (((int64_t)b * S + r0 + r) * S + col) * 3;
+            o[0] = (uint8_t)clip8_fixed(acc[r][0]);
+            o[1] = (uint8_t)clip8_fixed(acc[r][1]);
+            o[2] = (uint8_t)clip8_fixed(acc[r][2]);
+        }
+}
+
+static inline void launch_resize_crop(hipStream_t st, int max_ksx, const uint8_t* src, int64_t blob_bytes,
+                                      const ResizeDesc* desc, const int32_t* pool, const int32_t* bounds, uint8_t* dst,
+                                      int S, int nb) {
+    const dim3 grid((S + MMISS_RESIZE_ROWS - 1) / MMISS_RESIZE_ROWS, (S + 255) / 256, nb), block(256);
+    if (blob_bytes >= 4 && max_ksx <= 12)
+        hipLaunchKernelGGL(resize_crop_kernel<12>, grid, block, 0, st, src, blob_bytes, desc, pool, bounds, dst, S);
+    else if (blob_bytes >= 4 && max_ksx <= 24)
+        hipLaunchKernelGGL(resize_crop_kernel<24>, grid, block, 0, st, src, blob_bytes, desc, pool, bounds, dst, S);
+    else
+        hipLaunchKernelGGL(resize_crop_kernel<0>, grid, block, 0, st, src, blob_bytes, desc, pool, bounds, dst, S);
 }
 
 // Host geometry, the arithmetic of HF's get_resize_output_image_size (shortest edge -> S, long edge
