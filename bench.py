@@ -266,8 +266,18 @@ def main():
             e1 = enc.encode_image(host_px)            # host pixels in, host embedding out (PCIe both ways + sync)
             index.query(e1, K_TOP)
         host_ms = (time.perf_counter() - t0) / 20 * 1e3
+        _lib.prof_filter(None, 1)
+        _lib.prof_enable(True)
+        _lib.prof_reset()
+        for _ in range(5):
+            one_image_query()
+        torch.cuda.synchronize()
+        one_kernels = sorted(([k["kernel"], k["launches"] // 5, round(k["ms"] / 5 * 1e3, 1)] for k in _lib.prof_read()),
+                             key=lambda r: -r[2])
+        _lib.prof_enable(False)
         latency = {"image_encode_plus_top10_ms_device_resident": round(img_ms, 3),
                    "image_encode_plus_top10_ms_host_buffers": round(host_ms, 3), "batch": 1,
+                   "kernels_per_request": one_kernels, "kernels_per_request_columns": ["kernel", "launches", "us"],
                    "note": "the reference runs batch 1 on the CPU (backend/app/utils.py:76-77)"}
 
     # ---------------------------------------------------------------- ingest: raw RGB uploads -> embeddings

@@ -511,8 +511,23 @@ static int launch_gemm_bm(hipStream_t st, int bm, const void* A, const void* W, 
 }
 
 // bf16 GEMM of the CLIP towers. `bm` = tile height (128/160/192; 0 = 128); M must be a multiple of it.
+// gemm_skinny.h (included at the end of this header): the M <= 256 path
+static inline bool gemm_skinny_ok(int epi, int mv, int N, int K, const GemmEpi& ep);
+static int launch_gemm_skinny(hipStream_t st, int epi, const void* A, const void* W, const GemmEpi& ep, int mv, int N, int K);
+
 static int launch_gemm(hipStream_t st, int epi, int bm, const void* A, const void* W, const GemmEpi& ep, int M, int N,
                        int K) {
+    if (M > 0 && N > 0 && K > 0) {
+        const int mv0 = ep.m_valid < M ? ep.m_valid : M;
+        if (gemm_skinny_ok(epi, mv0, N, K, ep)) {
+            static const char* snames[] = {"gemm_skinny_f32", "gemm_skinny_bias", "gemm_skinny_bias_qgelu",
+                                           "gemm_skinny_bias_resid", "gemm_skinny_patch"};
+            const int oe = (epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16) ? 2 : 4;
+            MM_PROF(snames[epi], st, gemm_flops(mv0, N, K),
+                    2.0 * ((double)mv0 * K + (double)N * K) + (double)oe * mv0 * N * (epi == MMISS_EPI_BIAS_RESID_F32 ? 2 : 1));
+            return launch_gemm_skinny(st, epi, A, W, ep, mv0, N, K);
+        }
+    }
     if (bm == 0) bm = 128;
     if (M <= 0 || N <= 0 || K <= 0 || (M % bm) || (N % GEMM_BN) || (K % GEMM_BK))
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, bm, GEMM_BN,
@@ -533,3 +548,5 @@ static int launch_gemm(hipStream_t st, int epi, int bm, const void* A, const voi
         default: return launch_gemm_bm<__bf16, MMISS_EPI_PATCH_F32>(st, bm, A, W, ep, M, N, K);
     }
 }
+
+#include "gemm_skinny.h"

@@ -96,7 +96,11 @@ def test_gemm_256_tile_pipeline(env, M, N, K):
     # bit-identical to the 128-row kernel: same per-element k order
     o128 = torch.zeros(M, N, device="cuda")
     o256 = torch.zeros(M, N, device="cuda")
-    _gemm(env, _lib.EPI_F32, A, W, o128, bm=128)
+    _lib.set_option("gemm_skinny", 0)  # M = 256 would otherwise take the weight-streaming kernel
+    try:
+        _gemm(env, _lib.EPI_F32, A, W, o128, bm=128)
+    finally:
+        _lib.set_option("gemm_skinny", 1)
     _gemm(env, _lib.EPI_F32, A, W, o256, bm=256)
     assert torch.equal(o128, o256)
 
@@ -183,6 +187,66 @@ def test_gemm_residual_and_patch(env):
     acc = (A.float() @ W.float().T).reshape(imgs, G, N) + pos[1:][None]
     assert torch.allclose(out.reshape(imgs, T, N)[:, 1:], acc, rtol=1e-5, atol=2e-4)
     assert torch.equal(out.reshape(imgs, T, N)[:, 0], torch.zeros(imgs, N, device="cuda"))
+
+
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 50, 77, 129, 200, 256])
+def test_gemm_skinny_all_epilogues(env, M):
+    """M <= 256 rows take the weight-streaming kernel (gemm_skinny.h): the reference's one-request-at-a-time regime
+    (50 / <=77 token rows), the pruned last layer and the projection head. Same fp32 restatement, same tolerances."""
+    torch, _lib, lib = env
+    N, K = 384, 768
+    _lib.set_option("gemm_skinny_max_m", 256)  # the dispatch stops at 128 rows; the kernel itself goes to 256
+    g = torch.Generator(device="cuda").manual_seed(100 + M)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    acc = A.float() @ W.float().T
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _gemm(env, _lib.EPI_F32, A, W, out)
+    assert (out - acc).abs().max().item() <= 2e-4 * max(1.0, acc.abs().max().item())
+    ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    _gemm(env, _lib.EPI_BIAS_BF16, A, W, ob, bias=bias)
+    assert torch.allclose(ob.float(), acc + bias, rtol=2 ** -8, atol=1e-3)
+    og = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, og, bias=bias)
+    ref = acc + bias
+    assert torch.allclose(og.float(), ref * torch.sigmoid(1.702 * ref), rtol=2 ** -7, atol=2e-3)
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    x = x0.clone()
+    _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias)
+    assert torch.allclose(x, x0 + acc + bias, rtol=1e-5, atol=2e-4)
+    # the tiled kernel on the same operands (option gemm_skinny = 0), rows padded to its tile height
+    Mp = (M + 127) // 128 * 128
+    Ap = torch.zeros(Mp, K, device="cuda", dtype=torch.bfloat16)
+    Ap[:M] = A
+    outp = torch.zeros(Mp, N, device="cuda")
+    _lib.set_option("gemm_skinny", 0)
+    try:
+        _gemm(env, _lib.EPI_F32, Ap, W, outp)
+    finally:
+        _lib.set_option("gemm_skinny", 1)
+        _lib.set_option("gemm_skinny_max_m", 0)
+    assert (outp[:M] - out).abs().max().item() <= 2e-4 * max(1.0, acc.abs().max().item())
+
+
+def test_gemm_skinny_patch_epilogue_and_determinism(env):
+    torch, _lib, lib = env
+    G, T, imgs, N, K = 49, 50, 3, 256, 3072
+    M = G * imgs  # 147 rows
+    _lib.set_option("gemm_skinny_max_m", 256)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    pos = torch.randn(T, N, device="cuda", generator=g)
+    out = torch.zeros(imgs * T, N, device="cuda")
+    _gemm(env, _lib.EPI_PATCH_F32, A, W, out, aux=pos, p0=G, p1=T)
+    acc = (A.float() @ W.float().T).reshape(imgs, G, N) + pos[1:][None]
+    assert torch.allclose(out.reshape(imgs, T, N)[:, 1:], acc, rtol=1e-5, atol=3e-4)
+    assert torch.equal(out.reshape(imgs, T, N)[:, 0], torch.zeros(imgs, N, device="cuda"))
+    again = torch.zeros(imgs * T, N, device="cuda")
+    _gemm(env, _lib.EPI_PATCH_F32, A, W, again, aux=pos, p0=G, p1=T)
+    _lib.set_option("gemm_skinny_max_m", 0)
+    assert torch.equal(out, again)  # the K-quarters are summed in a fixed order
 
 
 @pytest.mark.parametrize("d", [128, 512, 768, 1024])
