@@ -266,6 +266,22 @@ def main():
             e1 = enc.encode_image(host_px)            # host pixels in, host embedding out (PCIe both ways + sync)
             index.query(e1, K_TOP)
         host_ms = (time.perf_counter() - t0) / 20 * 1e3
+        one_ids = ids_d[:1, :16].contiguous().clone()   # a short prompt: BOS + 14 tokens + EOS (padding trimmed)
+        one_ids[0, 15] = 49407
+        one_ids[0, 1:15] = torch.clamp(one_ids[0, 1:15], max=49405)
+
+        def one_text_query():
+            enc.encode_text(one_ids, out=one_emb)
+            return index.query(one_emb, K_TOP)
+
+        for _ in range(5):
+            one_text_query()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            one_text_query()
+        torch.cuda.synchronize()
+        txt_ms = (time.perf_counter() - t0) / 50 * 1e3
         _lib.prof_filter(None, 1)
         _lib.prof_enable(True)
         _lib.prof_reset()
@@ -276,7 +292,8 @@ def main():
                              key=lambda r: -r[2])
         _lib.prof_enable(False)
         latency = {"image_encode_plus_top10_ms_device_resident": round(img_ms, 3),
-                   "image_encode_plus_top10_ms_host_buffers": round(host_ms, 3), "batch": 1,
+                   "image_encode_plus_top10_ms_host_buffers": round(host_ms, 3),
+                   "text16_encode_plus_top10_ms_device_resident": round(txt_ms, 3), "batch": 1,
                    "kernels_per_request": one_kernels, "kernels_per_request_columns": ["kernel", "launches", "us"],
                    "note": "the reference runs batch 1 on the CPU (backend/app/utils.py:76-77)"}
 

@@ -35,3 +35,30 @@ for _ in range(n):
     enc.encode_image(px, out=emb)
 torch.cuda.synchronize()
 print({"ms_per_encode_only": round((time.perf_counter() - t0) / n * 1e3, 4)})
+
+# ---- the same request captured in a HIP graph (torch.cuda.CUDAGraph on the library's stream = torch's current stream)
+try:
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            enc.encode_image(px, out=emb)
+            lab, dist, cnt = index.query(emb, 10)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            enc.encode_image(px, out=emb)
+            lab, dist, cnt = index.query(emb, 10)
+    torch.cuda.synchronize()
+    ref_lab = index.query(emb, 10)[0].clone()
+    for _ in range(10):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g.replay()
+    torch.cuda.synchronize()
+    print({"ms_per_request_graph_replay": round((time.perf_counter() - t0) / n * 1e3, 4),
+           "same_result": bool(torch.equal(lab, ref_lab))})
+except Exception as e:  # noqa: BLE001
+    print({"graph_capture_failed": repr(e)})
