@@ -1,0 +1,30 @@
+"""bench.py's N > 1 control flow (barriers, rank-0-only sections, sharded retrieval + all-gather merge) rehearsed with
+two ranks on the one GPU of the test box over gloo (MMISS_DIST_BACKEND=gloo); the driver runs the same file over RCCL
+on 2/4/8 GPUs. Guards against a collective inside a rank-0-only branch, which deadlocks or kills the job."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_gloo_dry_run():
+    env = dict(os.environ, MMISS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--retrieval-rows", "200000"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["unit"] == "images/s" and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 512
+    assert out["retrieval"]["rows"] == 200000 and out["retrieval"]["rows_per_gpu"] == 100000
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"] is None  # the CPU baseline runs at N = 1 only
