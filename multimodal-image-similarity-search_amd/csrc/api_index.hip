@@ -443,8 +443,15 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         ep.out = ix->gmax.p; ep.ldo = ng; ep.m_valid = Q; ep.p0 = (int)N; ep.m_fast = 1;
         {
             MM_PROF("score_gemm_f16", st, 2.0 * Q * (double)N * D, (double)N * D * 2);
-            if (big)
-                MM_TRY((launch_gemm256_inst<_Float16, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D)));
+            if (big) {
+                // consecutive N-tiles per workgroup: long enough to amortise the pipeline fill, short enough to leave
+                // >= 8 workgroups per CU for balance
+                const int64_t tiles = (Npad / 256) * (Mq / 256);
+                int strip = (int)std::min<int64_t>(32, std::max<int64_t>(1, tiles / 2048));
+                const int forced = mmiss_option("score_strip", 0);
+                if (forced > 0) strip = forced;
+                MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip)));
+            }
             else
                 MM_TRY((launch_gemm_inst<_Float16, 128, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D)));
         }

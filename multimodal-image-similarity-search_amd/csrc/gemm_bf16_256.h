@@ -155,11 +155,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ 
         G256_WAIT(full);
         G256_BARRIER();
     }
-#undef G256_READ_A
-#undef G256_READ_W
-#undef G256_MMA
-#undef G256_WAIT
-#undef G256_BARRIER
 
     if constexpr (EPI == MMISS_EPI_GROUPMAX_F32) {
         // same group numbering as the 128-row kernel: g = (64-column block index) * 4 + fg (groupmax_row decodes it)
@@ -183,6 +178,166 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ 
     } else {
         gemm_epilogue<EPI, 8>(ep, acc, bm * 256 + wm * 128, bn * 256 + wn * 64, smem + wave * EPI_PATCH_BYTES, lane);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Strip variant for the retrieval score GEMM (GROUPMAX epilogue only): with K = 512 a 256x256 tile is just 8 K-tiles,
+// and with one workgroup per CU every tile paid its own pipeline fill (7 slot loads from cold), its drain (the last
+// two K-tiles wait on vmcnt(0)) and a workgroup launch - about a quarter of the 18 us per tile. Here a workgroup walks
+// `strip` consecutive 256-row N-tiles of the index for one 256-query M-tile as ONE continuous K-tile stream: the
+// staging of the next N-tile's first K-tiles is issued by the ordinary t+1 / t+2 prefetch of the last two K-tiles of
+// the current one, the group-max epilogue (registers and global stores only, no LDS) runs while those loads fly, and
+// the accumulators are simply zeroed. Sibling workgroups (the other M-tiles of the same strip) are adjacent in launch
+// order, so the index rows still come from HBM once and from L2 for the rest.
+template <typename IN>
+__global__ __launch_bounds__(512, 2) void gemm256_strip_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M,
+                                                               int N, int K, int strip, GemmEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename MfmaIn<IN>::frag frag;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nbm = M >> 8, nbn = N >> 8;
+    const int nstrips = (nbn + strip - 1) / strip;
+    const int wg = xcd_remap(blockIdx.x, nbm * nstrips);
+    const int sidx = wg / nbm, bm = wg - sidx * nbm;   // m fastest: the M-tiles of one strip run side by side
+    const int bn0 = sidx * strip;
+    const int ntiles = (nbn - bn0 < strip) ? nbn - bn0 : strip;
+    const IN* Ab = A + (size_t)bm * 256 * K;
+    const IN* Wb = W + (size_t)bn0 * 256 * K;
+    const int nt = K / GEMM_BK;
+    const int T = ntiles * nt;  // K-tiles of the whole strip
+
+    const int r_in = lane >> 3, p = lane & 7;
+    const int src_chunk = (p ^ r_in) * 8;
+    const int a_row0 = (wave >> 2) * 128 + (wave & 3) * 16 + r_in;
+    const int w_row0 = (wave >> 1) * 64 + (wave & 1) * 16 + r_in;
+    // stage slot `which` of buffer b with stream position (tile, kt); `live` = the position exists
+    auto stage = [&](int which, int b, int tile, int kt, bool live) {
+        if (!live) return;
+        char* dst = smem + (b * 4 + which) * G256_SLOT + wave * 2048;
+        const size_t koff = (size_t)kt * GEMM_BK + src_chunk;
+        if (which < 2) {
+            const IN* src = Ab + (size_t)(a_row0 + which * 64) * K + koff;
+            glds16(src, dst);
+            glds16(src + (size_t)8 * K, dst + 1024);
+        } else {
+            const IN* src = Wb + ((size_t)tile * 256 + w_row0 + (which - 2) * 32) * K + koff;
+            glds16(src, dst);
+            glds16(src + (size_t)8 * K, dst + 1024);
+        }
+    };
+
+    frag am[4][2];
+    frag wq[2][2][2];
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int a_off[4][2], w_off[2][2];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        const int row = wm * 64 + mf * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) a_off[mf][s] = row * 128 + (((4 * s + fg) ^ (row & 7)) << 4);
+    }
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+        const int row = wn * 32 + nf * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w_off[nf][s] = row * 128 + (((4 * s + fg) ^ (row & 7)) << 4);
+    }
+
+    // stream positions of t+1 and t+2, advanced once per K-tile (no division in the loop)
+    int kt1 = (nt > 1) ? 1 : 0, tile1 = (nt > 1) ? 0 : 1;
+    int kt2 = (nt > 2) ? 2 : (2 % nt), tile2 = 2 / nt;
+    // prologue: stream position 0 completely, position 1 except its m1 slot
+    stage(0, 0, 0, 0, true); stage(2, 0, 0, 0, true); stage(3, 0, 0, 0, true); stage(1, 0, 0, 0, true);
+    stage(0, 1, tile1, kt1, T > 1); stage(2, 1, tile1, kt1, T > 1); stage(3, 1, tile1, kt1, T > 1);
+    G256_WAIT(T >= 2);
+    G256_BARRIER();
+
+    int kt = 0, tile = 0;
+    for (int t = 0; t < T; ++t) {
+        const int b = t & 1;
+        const bool full = (t + 2 < T);
+        const bool live1 = (t + 1 < T);
+        // phase 0: quadrant (m0, n0)
+        G256_READ_A(b, 0);
+        G256_READ_W(b, 0);
+        stage(1, b ^ 1, tile1, kt1, live1);
+        G256_MMA(0, 0);
+        G256_WAIT(full);
+        G256_BARRIER();
+        // phase 1: quadrant (m0, n1)
+        G256_READ_W(b, 1);
+        stage(0, b, tile2, kt2, full);
+        G256_MMA(0, 1);
+        G256_WAIT(full);
+        G256_BARRIER();
+        // phase 2: quadrant (m1, n1)
+        G256_READ_A(b, 1);
+        stage(2, b, tile2, kt2, full);
+        G256_MMA(1, 1);
+        G256_BARRIER();
+        // phase 3: quadrant (m1, n0)
+        stage(3, b, tile2, kt2, full);
+        G256_MMA(1, 0);
+        G256_WAIT(full);
+        G256_BARRIER();
+        if (++kt1 == nt) { kt1 = 0; ++tile1; }
+        if (++kt2 == nt) { kt2 = 0; ++tile2; }
+        if (++kt == nt) {
+            // ---- this N-tile is complete: group maxima out (same numbering as gemm256_kernel), accumulators reset
+            const int bn = bn0 + tile;
+            const int g = (bn * 4 + wn) * 4 + fg;
+            const int n0 = bn * 256 + wn * 64 + 4 * fg;
+            float* out = reinterpret_cast<float*>(ep.out);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (n0 + i * 16 + r < ep.p0) ? acc[i][j][r] : -INFINITY;
+                        mx = fmaxf(mx, v);
+                        acc[i][j][r] = 0.f;
+                    }
+                const int m = bm * 256 + wm * 128 + j * 16 + fr;
+                if (m < ep.m_valid) out[(size_t)m * ep.ldo + g] = mx;
+            }
+            kt = 0;
+            ++tile;
+        }
+    }
+}
+#undef G256_READ_A
+#undef G256_READ_W
+#undef G256_MMA
+#undef G256_WAIT
+#undef G256_BARRIER
+
+template <typename IN>
+static int launch_gemm256_strip(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
+                                int strip) {
+    if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % GEMM_BK) || strip < 1)
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256_strip: M=%d N=%d K=%d strip=%d", M, N, K, strip);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_strip_kernel<IN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+        attr_done = true;
+    }
+    const int nbn = N / 256;
+    const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
+    hipLaunchKernelGGL((gemm256_strip_kernel<IN>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                       reinterpret_cast<const IN*>(W), M, N, K, strip, ep);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
 }
 
 template <typename IN, int EPI>

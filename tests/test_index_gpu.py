@@ -103,6 +103,29 @@ def test_batched_query_path_f16(mods, N, D, Q, k):
     _check(idx, ro, ro.normalize_rows(c, "f16"), labels, q, k)
 
 
+@pytest.mark.parametrize("strip", [1, 3, 5, 32])
+def test_score_gemm_strips(mods, strip):
+    """Q > 128 scores through the strip-persistent 256x256 kernel: a workgroup walks `strip` consecutive 256-row tiles
+    of the index as one K-tile stream. Any strip length (dividing the tile count or not, longer than it or not) must
+    give the oracle's answer; 35000 rows = 137 tiles, the last one partly padding."""
+    FlatIndex, _, _, ro = mods
+    from mmiss_amd import _lib
+
+    N, D, Q, k = 35000, 512, 300, 10
+    c = _corpus(N, D, seed=77)
+    labels = np.arange(N, dtype=np.int64) * 2 + 1
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    stored = ro.normalize_rows(c, "f16")
+    q = _corpus(Q, D, seed=78)
+    q[:40] = c[1000:1040] + 0.01 * q[:40]  # some queries with a clear nearest row
+    _lib.set_option("score_strip", strip)
+    try:
+        _check(idx, ro, stored, labels, q, k)
+    finally:
+        _lib.set_option("score_strip", 0)
+
+
 def test_batched_path_with_exact_duplicates(mods):
     """Many identical rows spread over several 16-row groups: group maxima tie exactly, the k smallest labels win."""
     FlatIndex, _, _, ro = mods
