@@ -122,7 +122,11 @@ def test_gemm_ring_pipeline(env, bm, M, N, K):
         assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item()), rep
     if K % 64 == 0:
         base = torch.zeros(M, N, device="cuda")
-        _gemm(env, _lib.EPI_F32, A, W, base, bm=bm)
+        _lib.set_option("gemm_skinny", 0)  # small M would otherwise take the weight-streaming kernel
+        try:
+            _gemm(env, _lib.EPI_F32, A, W, base, bm=bm)
+        finally:
+            _lib.set_option("gemm_skinny", 1)
         assert torch.equal(out, base)
     x0 = torch.randn(M, N, device="cuda", generator=g)
     x = x0.clone()
