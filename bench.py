@@ -333,6 +333,44 @@ def main():
                   "resize_crop_gbs": round((B * IH * IW * 3 + B * 224 * 224 * 3) / (rz_ms * 1e-3) / 1e9, 1) if rz_ms else None,
                   "note": "resize(shortest edge 224, bicubic, Pillow-exact) + centre crop + rescale + normalise + ViT-B/32"}
 
+    # ---------------------------------------------------------------- the reference's own checkpoint geometry (N = 1 only)
+    l14 = None
+    if rank == 0 and world == 1 and not args.no_text:
+        from mmiss_amd.encoder import LONGCLIP_L14
+
+        del raw, iemb
+        BL, BT = 128, 64
+        enc_l = ClipEncoder(LONGCLIP_L14, device=local_rank, max_batch_image=BL, max_batch_text=BT)
+        enc_l.load_state_dict(random_state_dict(LONGCLIP_L14, seed=0))
+        xl = torch.randn(BL, 3, 224, 224, device=dev)
+        ol = torch.empty(BL, 768, device=dev)
+
+        def timed(fn, warm, iters):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / iters
+
+        dt_img = timed(lambda: enc_l.encode_image(xl, out=ol), 2, 5)
+        idl = np.full((BT, 248), 49407, dtype=np.int32)
+        idl[:, 0] = 49406
+        idl[:, 1:247] = np.random.Generator(np.random.Philox(9)).integers(0, 49406, size=(BT, 246))
+        idl_d = torch.from_numpy(idl).to(dev)
+        otl = torch.empty(BT, 768, device=dev)
+        dt_txt = timed(lambda: enc_l.encode_text(idl_d, out=otl), 2, 5)
+        x1, o1 = xl[:1].contiguous(), torch.empty(1, 768, device=dev)
+        dt_one = timed(lambda: enc_l.encode_image(x1, out=o1), 3, 20)
+        l14 = {"model": "LongCLIP-L/14 geometry (reference CLIP_MODEL_ID, backend/app/utils.py:16-17): ViT-L/14 vision, "
+                        "248-token text tower, proj 768; random-init bf16",
+               "images_per_s_bs128": round(BL / dt_img, 1), "image_tflops": round(BL * 162.03e9 / dt_img / 1e12, 1),
+               "texts_per_s_bs64_T248": round(BT / dt_txt, 1), "text_tflops": round(BT * 44.39e9 / dt_txt / 1e12, 1),
+               "single_image_encode_ms": round(dt_one * 1e3, 3)}
+        del enc_l, xl, ol
+
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -353,7 +391,7 @@ def main():
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),
-            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest, "l14": l14, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

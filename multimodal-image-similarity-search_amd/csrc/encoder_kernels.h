@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
 
     const int fr = lane & 15, fg = lane >> 4;
     const int nqt = (T + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    // gridDim.y workgroups share one (b, h): small batches split the query tiles so that the grid still fills the chip
+    for (int qt = wave + 4 * blockIdx.y; qt < nqt; qt += 4 * gridDim.y) {
         const int q = qt * 16 + fr;
         bf16x8 qf[2];
 #pragma unroll
@@ -416,6 +417,12 @@ static int launch_im2col(hipStream_t st, const void* pixels, bool src_u8, void* 
 template <int NKP>
 static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int B, int T, int H, bool causal) {
     const int lds = NKP * 32 * (128 + ATT_VSTRIDE);
+    // query-tile splits per (b, h): 1 once B*H covers the 256 CUs (one ViT-L/14 image: 16 heads x 17 query tiles ->
+    // 5 splits = 80 workgroups instead of 16 walking 5 tiles each)
+    const int rounds = ((T + 15) / 16 + 3) / 4;
+    int qs = 256 / (B * H);
+    qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
+    const dim3 grid(B * H, qs);
     if (causal) {
         static bool done = false;
         if (!done) {
@@ -423,7 +430,7 @@ static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             done = true;
         }
-        hipLaunchKernelGGL((attention_kernel<NKP, true>), dim3(B * H), dim3(256), lds, st, (const uint16_t*)qkv,
+        hipLaunchKernelGGL((attention_kernel<NKP, true>), grid, dim3(256), lds, st, (const uint16_t*)qkv,
                            (uint16_t*)ctx, T, H);
     } else {
         static bool done = false;
@@ -432,7 +439,7 @@ static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             done = true;
         }
-        hipLaunchKernelGGL((attention_kernel<NKP, false>), dim3(B * H), dim3(256), lds, st, (const uint16_t*)qkv,
+        hipLaunchKernelGGL((attention_kernel<NKP, false>), grid, dim3(256), lds, st, (const uint16_t*)qkv,
                            (uint16_t*)ctx, T, H);
     }
     MM_HIP(hipGetLastError());

@@ -64,3 +64,13 @@ torch.cuda.synchronize()
 for k in sorted(_lib.prof_read(), key=lambda k: -k["ms"])[:8]:
     us = k["ms"] / k["launches"] * 1e3
     print(f'{k["kernel"]:26s} x{k["launches"] // 2:3d} {us:9.1f} us {k["flops"] / k["launches"] / (us * 1e-6) / 1e12:7.1f} TF')
+_lib.prof_enable(True)
+_lib.prof_reset()
+for _ in range(5):
+    enc.encode_image(x1, out=o1)
+torch.cuda.synchronize()
+print("--- one image")
+for k in sorted(_lib.prof_read(), key=lambda k: -k["ms"])[:10]:
+    us = k["ms"] / k["launches"] * 1e3
+    print(f'{k["kernel"]:26s} x{k["launches"] // 5:3d} {us:9.1f} us  total {us * (k["launches"] // 5):8.1f}')
+_lib.prof_enable(False)
