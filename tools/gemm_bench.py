@@ -15,6 +15,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 M0 = B * 50
 shapes = [("qkv", _lib.EPI_BIAS_BF16, 2304, 768), ("out", _lib.EPI_BIAS_RESID_F32, 768, 768),
           ("fc1", _lib.EPI_BIAS_QGELU_BF16, 3072, 768), ("fc2", _lib.EPI_BIAS_RESID_F32, 768, 3072)]
+if len(sys.argv) > 2 and sys.argv[2] == "l14":  # ViT-L/14: 257 tokens per image
+    M0 = B * 257
+    shapes = [("L14 qkv", _lib.EPI_BIAS_BF16, 3072, 1024), ("L14 out", _lib.EPI_BIAS_RESID_F32, 1024, 1024),
+              ("L14 fc1", _lib.EPI_BIAS_QGELU_BF16, 4096, 1024), ("L14 fc2", _lib.EPI_BIAS_RESID_F32, 1024, 4096)]
 res = []
 for name, epi, N, K in shapes:
     for bm in (128, 160, 192, 256, 1128, 1160, 1192):
