@@ -202,8 +202,12 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     const int d = tw.hidden, M = B * tw.T;
     const float eps = e->cfg.ln_eps;
     // per-GEMM tile height (fills the 256 CUs x 2 blocks evenly) and the row count padded to it
-    const int bm_qkv = gemm_pick_bm(M, 3 * d), bm_d = gemm_pick_bm(M, d), bm_mlp = gemm_pick_bm(M, tw.mlp);
-    auto padded = [&](int bm) { return (int)round_up(M, bm); };
+    // the LayerNorm-fused / folded GEMMs (ln_mode 1, 2) exist for the 128-column tiles only
+    const bool plain = e->ln_mode == 0;
+    const int bm_qkv = plain ? gemm_pick_variant(M, 3 * d) : gemm_pick_bm(M, 3 * d);
+    const int bm_d = plain ? gemm_pick_variant(M, d) : gemm_pick_bm(M, d);
+    const int bm_mlp = plain ? gemm_pick_variant(M, tw.mlp) : gemm_pick_bm(M, tw.mlp);
+    auto padded = [&](int bm) { return (int)round_up(M, bm % 1000); };
     auto tap = [&](int which) -> int {
         if (e->record_taps && tw.taps.p)
             MM_HIP(hipMemcpyAsync(tw.taps.as<float>() + (size_t)which * tw.tap_stride, tw.x.p, (size_t)M * d * 4,
@@ -321,8 +325,8 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
     Tower& tw = e->vis;
     const int d = tw.hidden, S = e->cfg.v_image, P = e->cfg.v_patch;
     const int Mpatch = B * e->G * e->G;
-    const int bm_p = gemm_pick_bm(Mpatch, d);
-    const int Mpp = (int)round_up(Mpatch, bm_p);
+    const int bm_p = gemm_pick_variant(Mpatch, d);
+    const int Mpp = (int)round_up(Mpatch, bm_p % 1000);
     MM_TRY(launch_im2col(st, pix_dev, src_u8, e->patches.p, B, S, P, e->Kp));
     hipLaunchKernelGGL(cls_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, st, tw.x.as<float>(),
                        e->cls.as<float>(), tw.pos.as<float>(), B, tw.T, d);
@@ -784,7 +788,7 @@ extern "C" int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant
     GemmEpi ep{};
     ep.out = out; ep.bias = bias; ep.aux = aux; ep.ldo = N; ep.m_valid = M; ep.p0 = p0; ep.p1 = p1;
     if (variant == 256) return launch_gemm256(reinterpret_cast<hipStream_t>(hip_stream), epi, A, W, ep, M, N, K);
-    if (variant > 1000) return launch_gemm_ring(reinterpret_cast<hipStream_t>(hip_stream), epi, variant - 1000, A, W, ep, M, N, K);
+    if (variant > 1000 && variant < 2000) return launch_gemm_ring(reinterpret_cast<hipStream_t>(hip_stream), epi, variant - 1000, A, W, ep, M, N, K);
     return launch_gemm(reinterpret_cast<hipStream_t>(hip_stream), epi, variant, A, W, ep, M, N, K);
 }
 
@@ -800,7 +804,7 @@ extern "C" int mmiss_dbg_gemm_time(int device, int epi, int variant, const void*
     MM_HIP(hipEventCreate(&e1));
     auto run = [&]() -> int {
         if (variant == 256) return launch_gemm256(nullptr, epi, A, W, ep, M, N, K);
-        if (variant > 1000) return launch_gemm_ring(nullptr, epi, variant - 1000, A, W, ep, M, N, K);
+        if (variant > 1000 && variant < 2000) return launch_gemm_ring(nullptr, epi, variant - 1000, A, W, ep, M, N, K);
         return launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K);
     };
     for (int i = 0; i < 3; ++i) MM_TRY(run());

@@ -239,25 +239,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
 // fp32 statistics from ep.ln_stats, affine ep.ln_g / ep.ln_b), computed and rounded to bf16 while it is staged
 // through registers into the same swizzled LDS image. This removes the separate LayerNorm pass (59 MB per call at
 // B=256) and its kernel boundary; the W tile keeps its LDS-DMA path.
-template <typename IN, int BM, int EPI, bool ALN = false>
-__global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M,
-                                                        int N, int K, GemmEpi ep) {
+// NWN = waves along n (2: BM x 128 tile, 4 waves, two workgroups per CU; 4: BM x 256 tile, 8 waves, one workgroup per CU:
+// the A panel is staged once for 256 output columns instead of once per 128).
+template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2>
+__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void gemm16_kernel(const IN* __restrict__ A,
+                                                                             const IN* __restrict__ W, int M, int N, int K,
+                                                                             GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename MfmaIn<IN>::frag frag;
+    static_assert(NWN == 2 || (NWN == 4 && !ALN), "wide tiles have no fused-LayerNorm staging");
+    constexpr int BN = 64 * NWN, NWAVES = 2 * NWN;
     constexpr int JT = BM / 32;               // 16-row m sub-tiles per wave (wave tile = BM/2 x 64)
-    constexpr int A_BYTES = BM * 128, W_BYTES = GEMM_BN * 128, BUF = A_BYTES + W_BYTES;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
     constexpr int RPT = BM / 32;              // ALN: rows per thread (thread t: 16-byte chunk t&7 of rows (t>>3) + 32 i)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nbm = M / BM, nbn = N / GEMM_BN;
+    const int nbm = M / BM, nbn = N / BN;
     const int nwg = nbm * nbn;
     const int wg = xcd_remap(blockIdx.x, nwg);
     int bm, bn;
     tile_order(wg, nbm, nbn, ep.m_fast, bm, bn);
 
     const IN* Ab = A + (size_t)bm * BM * K;
-    const IN* Wb = W + (size_t)bn * GEMM_BN * K;
+    const IN* Wb = W + (size_t)bn * BN * K;
 
     // staging: one wave-instruction = 8 rows x 128 B; lane -> (row r_in, 16-B slot p); slot p of row r
     // holds global chunk p ^ (r & 7)
@@ -267,11 +272,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
         char* sA = smem + buf * BUF;
         char* sW = sA + A_BYTES;
         const size_t koff = (size_t)kt * GEMM_BK + src_chunk;
-        if constexpr (!ALN) {
+        if constexpr (!ALN && NWN == 2) {
 #pragma unroll
             for (int i = 0; i < BM / 32; ++i) {
                 const int rowblk = wave * (BM / 32) + i;
                 glds16(Ab + (size_t)(rowblk * 8 + r_in) * K + koff, sA + rowblk * 1024);
+            }
+        } else if constexpr (!ALN) {
+#pragma unroll
+            for (int i = 0; i < (BM / 8 + NWAVES - 1) / NWAVES; ++i) {
+                const int rowblk = wave + i * NWAVES;  // BM/8 row blocks dealt round-robin to the 8 waves
+                if (rowblk < BM / 8) glds16(Ab + (size_t)(rowblk * 8 + r_in) * K + koff, sA + rowblk * 1024);
             }
         }
 #pragma unroll
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
         }
     };
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int fr = lane & 15, fg = lane >> 4;
     f32x4 acc[4][JT];
 #pragma unroll
@@ -384,10 +395,10 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
 
     // acc[i][j][reg] = C[m = m_base + j*16][n = n_base + i*16 + reg]
     const int m_base = bm * BM + wm * (BM / 2) + fr;
-    const int n_base = bn * GEMM_BN + wn * 64 + 4 * fg;
+    const int n_base = bn * BN + wn * 64 + 4 * fg;
 
     if constexpr (EPI == MMISS_EPI_GROUPMAX_F32) {
-        const int g = (bn * 2 + wn) * 4 + fg;
+        const int g = (bn * NWN + wn) * 4 + fg;
         float* out = reinterpret_cast<float*>(ep.out);
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
@@ -406,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(const IN* __restrict__ A
     }
 
     // all waves are past the loop's last barrier: the staging buffers are dead, each wave takes a private patch
-    gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / 2), bn * GEMM_BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
-                           smem + 4 * EPI_PATCH_BYTES + wave * (JT * 16 * 8));
+    gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / 2), bn * BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
+                           smem + NWAVES * EPI_PATCH_BYTES + wave * (JT * 16 * 8));
 }
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
@@ -431,21 +442,49 @@ static inline int gemm_pick_bm(int64_t M_rows, int N) {
     return best;
 }
 
-template <typename IN, int BM, int EPI, bool ALN = false>
+// Tile VARIANT for launch_gemm: a tile height (128/160/192: BM x 128 tile, 4 waves, 2 workgroups per CU) or 2000 + BM
+// (BM x 256 tile, 8 waves, 1 workgroup per CU: the A panel is staged once per 256 columns). The wide tiles are 3-11 %
+// faster on the ViT-B/32 shapes as ISOLATED launches (160 x 256: QKV 51.8 vs 58.1 us, FC2 62.0 vs 66.8 us) but 8 % slower
+// inside the encode (3.49 vs 3.22 ms, tools/option_ab.py gemm_wide 0 1: a 106 KB-LDS workgroup cannot start on a CU until
+// the previous kernel has left it completely), so they are OFF by default (option gemm_wide = 1 turns the cost model on).
+static inline int gemm_pick_variant(int64_t M_rows, int N) {
+    int best = gemm_pick_bm(M_rows, N);
+    if ((N % 256) != 0 || mmiss_option("gemm_wide", 0) == 0) return best;
+    const double effn[3] = {1.00, 0.93, 0.89}, effw[3] = {0.97, 0.86, 0.84};
+    const int bms[3] = {128, 160, 192};
+    double best_cost = 1e300;
+    for (int v = 0; v < 3; ++v)
+        if (bms[v] == best) {
+            const double tiles = (double)((M_rows + best - 1) / best) * (N / GEMM_BN);
+            const double rounds = tiles <= 1024.0 ? (double)((int64_t)((tiles + 511.0) / 512.0)) : tiles / 512.0 + 0.5;
+            best_cost = rounds * best * effn[v];
+        }
+    for (int v = 0; v < 3; ++v) {
+        const double tiles = (double)((M_rows + bms[v] - 1) / bms[v]) * (N / 256);
+        const double rounds = tiles <= 512.0 ? (double)((int64_t)((tiles + 255.0) / 256.0)) : tiles / 256.0 + 0.5;
+        const double cost = rounds * bms[v] * effw[v];
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = 2000 + bms[v]; }
+    }
+    return best;
+}
+
+template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2>
 static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
-    constexpr int LDS = 2 * (BM + GEMM_BN) * 128 + (ALN ? BM * 8 : 0);
+    constexpr int BN = 64 * NWN;
+    constexpr int LDS = 2 * (BM + BN) * 128 + (ALN ? BM * 8 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN>),
+        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
     }
-    const int nwg = (M / BM) * (N / GEMM_BN);
+    if (N % BN) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: N=%d is not a multiple of the %d-column tile", N, BN);
+    const int nwg = (M / BM) * (N / BN);
     GemmEpi e2 = ep;
     const int forced = mmiss_option("gemm_group_m", -1);  // experiment knob (tools/gemm_order_sweep.py)
     if (forced >= 0 && e2.m_fast != 1) e2.m_fast = forced;
-    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN>), dim3(nwg), dim3(256), LDS, st, reinterpret_cast<const IN*>(A),
-                       reinterpret_cast<const IN*>(W), M, N, K, e2);
+    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN>), dim3(nwg), dim3(128 * NWN), LDS, st,
+                       reinterpret_cast<const IN*>(A), reinterpret_cast<const IN*>(W), M, N, K, e2);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }
@@ -506,6 +545,10 @@ static int launch_gemm_bm(hipStream_t st, int bm, const void* A, const void* W, 
         case 128: return launch_gemm_inst<IN, 128, EPI>(st, A, W, ep, M, N, K);
         case 160: return launch_gemm_inst<IN, 160, EPI>(st, A, W, ep, M, N, K);
         case 192: return launch_gemm_inst<IN, 192, EPI>(st, A, W, ep, M, N, K);
+        // 2000 + BM: the BM x 256 tile with 8 waves (one workgroup per CU)
+        case 2128: return launch_gemm_inst<IN, 128, EPI, false, 4>(st, A, W, ep, M, N, K);
+        case 2160: return launch_gemm_inst<IN, 160, EPI, false, 4>(st, A, W, ep, M, N, K);
+        case 2192: return launch_gemm_inst<IN, 192, EPI, false, 4>(st, A, W, ep, M, N, K);
     }
     MM_FAIL(MMISS_ERR_ARG, "gemm: unsupported tile height %d", bm);
 }
@@ -529,7 +572,7 @@ static int launch_gemm(hipStream_t st, int epi, int bm, const void* A, const voi
         }
     }
     if (bm == 0) bm = 128;
-    if (M <= 0 || N <= 0 || K <= 0 || (M % bm) || (N % GEMM_BN) || (K % GEMM_BK))
+    if (M <= 0 || N <= 0 || K <= 0 || (M % (bm % 1000)) || (N % GEMM_BN) || (K % GEMM_BK))
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: M=%d N=%d K=%d must be multiples of %d/%d/%d", M, N, K, bm, GEMM_BN,
                 GEMM_BK);
     static const char* names[] = {"gemm_bf16_f32", "gemm_bf16_bias", "gemm_bf16_bias_qgelu",

@@ -138,6 +138,36 @@ def test_gemm_ring_pipeline(env, bm, M, N, K):
     assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
 
 
+@pytest.mark.parametrize("bm,M,N,K", [(128, 256, 256, 64), (160, 320, 512, 192), (192, 768, 768, 768), (160, 1600, 2304, 768)])
+def test_gemm_wide_tile(env, bm, M, N, K):
+    """The BM x 256 tile with 8 waves (variant 2000 + BM): same arithmetic order per element as the BM x 128 tile, so
+    bit-identical to it, and all epilogues against the fp32 restatement."""
+    torch, _lib, lib = env
+    g = torch.Generator(device="cuda").manual_seed(bm + M + N + K)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().T
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _gemm(env, _lib.EPI_F32, A, W, out, bm=2000 + bm)
+    assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    base = torch.zeros(M, N, device="cuda")
+    _lib.set_option("gemm_skinny", 0)
+    try:
+        _gemm(env, _lib.EPI_F32, A, W, base, bm=bm)
+    finally:
+        _lib.set_option("gemm_skinny", 1)
+    assert torch.equal(out, base)
+    ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, ob, bias=bias, bm=2000 + bm)
+    r2 = ref + bias
+    assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
+    x0 = torch.randn(M, N, device="cuda", generator=g)
+    x = x0.clone()
+    _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias, bm=2000 + bm)
+    assert torch.allclose(x, x0 + ref + bias, rtol=1e-5, atol=2e-4)
+
+
 def test_gemm_asymmetric_layout(env):
     """A = identity-like, asymmetric W: catches a transposed or permuted C write (guide §3)."""
     torch, _lib, lib = env
