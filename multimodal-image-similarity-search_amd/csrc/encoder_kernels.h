@@ -244,8 +244,9 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const uint16_t* __
 // ------------------------------------------------------------------------------------------------
 #define ATT_VSTRIDE 144  // bytes per V row in LDS (128 + 16 pad: spreads the tr-read's 8 rows over banks)
 
+#define ATT_THREADS(NKP) ((NKP) > 4 ? 512 : 256)  // long sequences: 8 waves share one staged K/V image
 template <int NKP, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
+__global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
                                                         int T, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKP * 32;
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int dmodel = H * 64, ld = 3 * dmodel;
     const uint16_t* base = qkv + (size_t)b * T * ld + h * 64;
 
-    for (int idx = tid; idx < TP * 8; idx += 256) {
+    constexpr int NW = ATT_THREADS(NKP) / 64;
+    for (int idx = tid; idx < TP * 8; idx += NW * 64) {
         const int row = idx >> 3, c = idx & 7;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
         if (row < T) {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
     const int fr = lane & 15, fg = lane >> 4;
     const int nqt = (T + 15) >> 4;
     // gridDim.y workgroups share one (b, h): small batches split the query tiles so that the grid still fills the chip
-    for (int qt = wave + 4 * blockIdx.y; qt < nqt; qt += 4 * gridDim.y) {
+    for (int qt = wave + NW * blockIdx.y; qt < nqt; qt += NW * gridDim.y) {
         const int q = qt * 16 + fr;
         bf16x8 qf[2];
 #pragma unroll
@@ -279,6 +281,83 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
             u32x4 raw = {0u, 0u, 0u, 0u};
             if (q < T) raw = *reinterpret_cast<const u32x4*>(base + (size_t)q * ld + s * 32 + fg * 8);
             qf[s] = __builtin_bit_cast(bf16x8, raw);
+        }
+        if constexpr (NKP > 4) {
+            // ---- long sequences (ViT-L/14: 257 keys, LongCLIP text: 248): holding all 2*NKP score tiles costs 288 VGPRs
+            // (one wave per SIMD). Two passes instead - pass 1 only finds the row maxima, pass 2 recomputes each score
+            // tile, exponentiates it and feeds it straight to the PV MFMA - keep 2 tiles live (< 64 VGPRs); the extra
+            // QK^T MFMAs are cheap next to the occupancy. Same maxima, same exp arguments, same summation order as the
+            // one-pass form: bit-identical output.
+            auto score_tile = [&](int kt) -> f32x4 {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                const int krow = kt * 16 + fr;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int chunk = 4 * s + fg;
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((chunk ^ (krow & 7)) << 4));
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 16 + 4 * fg + r;
+                    const bool ok = (key < T) && (!CAUSAL || key <= q);
+                    a[r] = ok ? a[r] * 0.125f : -INFINITY;
+                }
+                return a;
+            };
+            float mx = -INFINITY;
+#pragma unroll 2
+            for (int kt = 0; kt < 2 * NKP; ++kt) {
+                const f32x4 a = score_tile(kt);
+                mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float l = 0.f;
+            f32x4 oacc[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll 1
+            for (int ks = 0; ks < NKP; ++ks) {
+                f32x4 p0 = score_tile(2 * ks), p1 = score_tile(2 * ks + 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p0[r] = __expf(p0[r] - mx); l += p0[r]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p1[r] = __expf(p1[r] - mx); l += p1[r]; }
+                u32x4 praw;
+                praw[0] = pack_bf16x2(p0[0], p0[1]);
+                praw[1] = pack_bf16x2(p0[2], p0[3]);
+                praw[2] = pack_bf16x2(p1[0], p1[1]);
+                praw[3] = pack_bf16x2(p1[2], p1[3]);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const char* a0 = sV + (32 * ks + 4 * fg + tq) * ATT_VSTRIDE + (dt * 16 + 4 * tp) * 2;
+                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(a0));
+                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(a0 + 16 * ATT_VSTRIDE));
+                    bf16x8 vf;
+                    vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                    vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+                }
+            }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+            if (q < T) {
+                uint16_t* orow = ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+                    pk[1] = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+                    *reinterpret_cast<u32x2*>(orow + dt * 16) = pk;
+                }
+            }
+            continue;
         }
         f32x4 sacc[2 * NKP];
         float mx = -INFINITY;
@@ -419,7 +498,8 @@ static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int 
     const int lds = NKP * 32 * (128 + ATT_VSTRIDE);
     // query-tile splits per (b, h): 1 once B*H covers the 256 CUs (one ViT-L/14 image: 16 heads x 17 query tiles ->
     // 5 splits = 80 workgroups instead of 16 walking 5 tiles each)
-    const int rounds = ((T + 15) / 16 + 3) / 4;
+    constexpr int NW = ATT_THREADS(NKP) / 64;
+    const int rounds = ((T + 15) / 16 + NW - 1) / NW;
     int qs = 256 / (B * H);
     qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
     const dim3 grid(B * H, qs);
@@ -430,7 +510,7 @@ static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             done = true;
         }
-        hipLaunchKernelGGL((attention_kernel<NKP, true>), grid, dim3(256), lds, st, (const uint16_t*)qkv,
+        hipLaunchKernelGGL((attention_kernel<NKP, true>), grid, dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
                            (uint16_t*)ctx, T, H);
     } else {
         static bool done = false;
@@ -439,7 +519,7 @@ static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
             done = true;
         }
-        hipLaunchKernelGGL((attention_kernel<NKP, false>), grid, dim3(256), lds, st, (const uint16_t*)qkv,
+        hipLaunchKernelGGL((attention_kernel<NKP, false>), grid, dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
                            (uint16_t*)ctx, T, H);
     }
     MM_HIP(hipGetLastError());

@@ -313,7 +313,8 @@ def _attn_ref(torch, qkv, B, T, H, causal):
     return (p @ v).transpose(1, 2).reshape(B * T, d)
 
 
-@pytest.mark.parametrize("B,T,H,causal", [(3, 50, 12, 0), (2, 77, 8, 1), (2, 16, 2, 1), (1, 5, 2, 0), (2, 257, 4, 0), (1, 248, 3, 1), (5, 33, 2, 1)])
+@pytest.mark.parametrize("B,T,H,causal", [(3, 50, 12, 0), (2, 77, 8, 1), (2, 16, 2, 1), (1, 5, 2, 0), (2, 257, 4, 0), (1, 248, 3, 1), (5, 33, 2, 1),
+                                            (2, 150, 2, 1), (1, 288, 2, 0), (40, 129, 16, 0)])
 def test_attention(env, B, T, H, causal):
     torch, _lib, lib = env
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
