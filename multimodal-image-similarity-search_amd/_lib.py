@@ -119,6 +119,10 @@ def load() -> C.CDLL:
         if lib.mmiss_abi_version() != 1:
             raise ImportError("libmmiss.so ABI version mismatch")
         _lib = lib
+        # experiment knobs from the environment: MMISS_OPTIONS="gemm_wide=1,scan_rounds=2" (see mmiss_dbg_set_option)
+        for kv in filter(None, os.environ.get("MMISS_OPTIONS", "").split(",")):
+            k, _, v = kv.partition("=")
+            lib.mmiss_dbg_set_option(k.strip().encode(), int(v))
         return lib
 
 

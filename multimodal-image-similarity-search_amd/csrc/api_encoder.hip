@@ -208,6 +208,10 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     const int bm_d = plain ? gemm_pick_variant(M, d) : gemm_pick_bm(M, d);
     const int bm_mlp = plain ? gemm_pick_variant(M, tw.mlp) : gemm_pick_bm(M, tw.mlp);
     auto padded = [&](int bm) { return (int)round_up(M, bm % 1000); };
+    // 256 x 256 phase-pipelined tile for the widest GEMMs: from N = 4096 (the ViT-L/14 FC1: 336 -> 320 us inside the bs-128
+    // encode, +2 % images/s; the L/14 QKV at N = 3072 and the B/32 GEMMs do not gain). Option gemm_256 = minimum N, 0 = never.
+    const int min_n256 = mmiss_option("gemm_256", 4096);
+    auto use256 = [&](int N) { return plain && min_n256 > 0 && N >= min_n256 && (N % 256) == 0 && (d % 64) == 0 && M > 512; };
     auto tap = [&](int which) -> int {
         if (e->record_taps && tw.taps.p)
             MM_HIP(hipMemcpyAsync(tw.taps.as<float>() + (size_t)which * tw.tap_stride, tw.x.p, (size_t)M * d * 4,
@@ -244,7 +248,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         } else {
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
-            MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
+            if (use256(3 * d)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_BF16, tw.h.p, L.wqkv.p, ep, padded(256), 3 * d, d));
+            else MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
         }
         MM_TRY(launch_attention(st, tw.qkv.p, tw.ctx.p, B, tw.T, tw.heads, causal));
         if (prune && l == tw.layers - 1) {
@@ -287,7 +292,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         } else {
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
-            MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.h.p, L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
+            if (use256(tw.mlp)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_QGELU_BF16, tw.h.p, L.w1.p, ep, padded(256), tw.mlp, d));
+            else MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.h.p, L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
         }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = M;

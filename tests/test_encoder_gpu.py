@@ -116,6 +116,30 @@ def test_patch14_padded_k_and_odd_token_count():
     assert (1 - _cos(enc.encode_image(px), co.embed_images(px, W, s))).max() < COS_TOL
 
 
+def test_wide_mlp_takes_the_256_tile_and_matches():
+    """FC1 with N >= 4096 (the ViT-L/14 MLP width) and more than 512 rows runs on the 256x256 phase-pipelined tile;
+    its per-element k order is that of the 128-column tile, so the embeddings must not change by a bit."""
+    import dataclasses
+    from mmiss_amd import _lib
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.TINY, v_patch=14, v_image=56, v_mlp=4096)  # 17 tokens x 32 images = 544 rows
+    W = co.init_weights(s, seed=6)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=32, max_batch_text=4)
+    enc.load_state_dict(W)
+    rng = np.random.Generator(np.random.Philox(80))
+    px = rng.standard_normal((32, 3, 56, 56), dtype=np.float32)
+    got = enc.encode_image(px)
+    assert (1 - _cos(got, co.embed_images(px, W, s))).max() < COS_TOL
+    _lib.set_option("gemm_256", 0)
+    try:
+        base = enc.encode_image(px)
+    finally:
+        _lib.set_option("gemm_256", 4096)
+    np.testing.assert_array_equal(got, base)
+
+
 def test_chunking_beyond_max_batch(tiny):
     enc, W, co = tiny
     s = co.TINY
