@@ -69,12 +69,7 @@ int64_t find_row(const mmiss_index* ix, int64_t label) {
 
 template <typename T, int NQT, int CAP, int GS = 8>
 int launch_scan_t(hipStream_t st, const ScanArgs& a, int slabs, int qtiles, int lds) {
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_topk_kernel<T, NQT, CAP, GS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_lds = lds;
-    }
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&scan_topk_kernel<T, NQT, CAP, GS>), lds));
     hipLaunchKernelGGL((scan_topk_kernel<T, NQT, CAP, GS>), dim3(slabs, qtiles), dim3(256), lds, st, a);
     MM_HIP(hipGetLastError());
     return MMISS_OK;

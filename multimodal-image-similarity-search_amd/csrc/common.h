@@ -58,6 +58,9 @@ int mmiss_option(const char* key, int dflt);
 
 // Make sure `device` is a usable gfx950 and current. Fails loudly otherwise (no CPU fallback).
 int mmiss_use_device(int device);
+// Raise a kernel's dynamic-LDS limit to `lds` bytes on the CURRENT device, once per (kernel, device): the attribute is
+// per device, so a process-wide "done" flag would leave the second GPU of a process at the 64 KB default.
+int mmiss_ensure_dyn_lds(const void* kernel, int lds);
 
 // ------------------------------------------------------------------ kernel timing (mmiss_prof_*)
 struct ProfScope {

@@ -504,21 +504,11 @@ static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int 
     qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
     const dim3 grid(B * H, qs);
     if (causal) {
-        static bool done = false;
-        if (!done) {
-            MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKP, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            done = true;
-        }
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<NKP, true>), lds));
         hipLaunchKernelGGL((attention_kernel<NKP, true>), grid, dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
                            (uint16_t*)ctx, T, H);
     } else {
-        static bool done = false;
-        if (!done) {
-            MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<NKP, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            done = true;
-        }
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<NKP, false>), lds));
         hipLaunchKernelGGL((attention_kernel<NKP, false>), grid, dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
                            (uint16_t*)ctx, T, H);
     }

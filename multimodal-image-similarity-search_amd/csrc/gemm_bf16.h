@@ -472,12 +472,7 @@ template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2>
 static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
     constexpr int BN = 64 * NWN;
     constexpr int LDS = 2 * (BM + BN) * 128 + (ALN ? BM * 8 : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN>), LDS));
     if (N % BN) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: N=%d is not a multiple of the %d-column tile", N, BN);
     const int nwg = (M / BM) * (N / BN);
     GemmEpi e2 = ep;

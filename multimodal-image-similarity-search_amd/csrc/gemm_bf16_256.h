@@ -326,12 +326,7 @@ static int launch_gemm256_strip(hipStream_t st, const void* A, const void* W, co
                                 int strip) {
     if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % GEMM_BK) || strip < 1)
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256_strip: M=%d N=%d K=%d strip=%d", M, N, K, strip);
-    static bool attr_done = false;
-    if (!attr_done) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_strip_kernel<IN>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
-        attr_done = true;
-    }
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256_strip_kernel<IN>), G256_LDS));
     const int nbn = N / 256;
     const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
     hipLaunchKernelGGL((gemm256_strip_kernel<IN>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
@@ -342,12 +337,7 @@ static int launch_gemm256_strip(hipStream_t st, const void* A, const void* W, co
 
 template <typename IN, int EPI>
 static int launch_gemm256_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<IN, EPI>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
-        attr_done = true;
-    }
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256_kernel<IN, EPI>), G256_LDS));
     const int nwg = (M / 256) * (N / 256);
     hipLaunchKernelGGL((gemm256_kernel<IN, EPI>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
                        reinterpret_cast<const IN*>(W), M, N, K, ep);

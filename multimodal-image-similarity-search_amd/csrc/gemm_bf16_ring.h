@@ -150,12 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm16r_kernel(const IN* __restrict__ 
 template <typename IN, int BM, int EPI>
 static int launch_gemm_ring_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
     constexpr int LDS = GR_NS * (BM + GEMM_BN) * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
-        MM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16r_kernel<IN, BM, EPI>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm16r_kernel<IN, BM, EPI>), LDS));
     const int nwg = (M / BM) * (N / GEMM_BN);
     hipLaunchKernelGGL((gemm16r_kernel<IN, BM, EPI>), dim3(nwg), dim3(256), LDS, st, reinterpret_cast<const IN*>(A),
                        reinterpret_cast<const IN*>(W), M, N, K, ep);

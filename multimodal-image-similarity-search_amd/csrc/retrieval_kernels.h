@@ -435,7 +435,7 @@ struct MergeArgs {
     int32_t* out_r;
 };
 
-// A wave streams 32 entries per step, so a list of <= kp (<= 32) entries can never outgrow its 64-slot
+// A wave streams 64 - kp entries per step, so a list of <= kp (<= 32) entries can never outgrow its 64-slot
 // buffer before the compaction that follows the step.
 __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
     __shared__ float cs[4][64];
@@ -451,17 +451,28 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
     int l_end = a.out_s ? l_begin + a.lists_per_block : a.L;
     if (l_end > a.L) l_end = a.L;
     const int64_t total = (int64_t)(l_end > l_begin ? l_end - l_begin : 0) * kp;
-    for (int64_t e0 = (int64_t)wave * 32; e0 < total; e0 += 128) {
-        const int64_t e = e0 + (lane & 31);
-        float s = SCAN_NEG_INF;
-        int r = -1;
-        if (lane < 32 && e < total) {
+    // A wave takes NL = 64 - kp entries per step (its 64-slot buffer holds at most kp survivors + NL newcomers) and loads
+    // the next step's entries before it files the current ones, so the global-load latency overlaps the LDS work.
+    const int NL = 64 - kp;
+    auto fetch = [&](int64_t e0, float& s, int& r) {
+        s = SCAN_NEG_INF;
+        r = -1;
+        const int64_t e = e0 + lane;
+        if (lane < NL && e < total) {
             const int64_t l = l_begin + e / kp;
             const int slot = (int)(e % kp);
             const size_t o = ((size_t)l * a.Q + q) * kp + slot;
             s = a.in_s[o];
             r = a.in_r[o];
         }
+    };
+    float s, sn;
+    int r, rn;
+    int64_t e0 = (int64_t)wave * NL;
+    fetch(e0, s, r);
+    while (e0 < total) {
+        const int64_t e1 = e0 + 4 * (int64_t)NL;
+        fetch(e1, sn, rn);
         if (r >= 0 && s > tau) {
             const int pos = atomicAdd(&cnt[wave], 1);
             cs[wave][pos] = s;
@@ -479,6 +490,9 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
             if (lane == 0) cnt[wave] = kp;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
+        e0 = e1;
+        s = sn;
+        r = rn;
     }
     __syncthreads();
     if (wave == 0) {

@@ -69,6 +69,20 @@ int mmiss_use_device(int device) {
 // ------------------------------------------------------------------ tuning options (tests / experiments)
 static std::mutex g_opt_mu;
 static std::map<std::string, int> g_opts;
+int mmiss_ensure_dyn_lds(const void* kernel, int lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> have;
+    int dev = 0;
+    MM_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    int& cur = have[std::make_pair(kernel, dev)];
+    if (lds > cur) {
+        MM_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        cur = lds;
+    }
+    return MMISS_OK;
+}
+
 int mmiss_option(const char* key, int dflt) {
     std::lock_guard<std::mutex> lk(g_opt_mu);
     auto it = g_opts.find(key);
