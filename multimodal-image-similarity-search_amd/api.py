@@ -14,8 +14,9 @@ files) are out of scope.
 
 The reference declares `Form`/`File` parameters, which need the `python-multipart` package; it is not installed in
 this image, so the routes read the raw body and parse multipart/form-data with the standard library.
-Image ids: the reference uses a perceptual hash (`imagehash.phash`, main.py:581-585, absent here); this stand-in
-uses `img_` + sha1 of the decoded RGB pixels — ids are bookkeeping, not similarity arithmetic.
+Image ids: the reference uses a perceptual hash (`imagehash.phash`, main.py:581-585; the package is absent here);
+`phash_hex` restates its published algorithm, so ids have the reference's form and the same image uploaded twice — in any
+lossless container — is a duplicate (409), as there.
 """
 import hashlib
 import json
@@ -81,9 +82,30 @@ def apply_filters(results: List[dict], filters: Optional[List[str]]) -> List[dic
     return kept
 
 
+def phash_hex(image, hash_size: int = 8, highfreq_factor: int = 4) -> str:
+    """Perceptual hash, restated from the published algorithm of `imagehash.phash` (the third-party package behind the
+    reference's generate_image_hash, main.py:581-585; absent here, so this restatement is unpinned): grayscale, LANCZOS
+    resize to 32x32, 2-D DCT-II, the 8x8 low-frequency corner thresholded at its median, bits row-major -> 16 hex digits.
+    Bookkeeping, not similarity arithmetic: it only decides which uploads count as duplicates (HTTP 409)."""
+    import numpy as np
+    from PIL import Image
+    from scipy.fft import dct
+
+    size = hash_size * highfreq_factor
+    pixels = np.asarray(image.convert("L").resize((size, size), Image.Resampling.LANCZOS), dtype=np.float64)
+    low = dct(dct(pixels, axis=0, type=2), axis=1, type=2)[:hash_size, :hash_size]
+    bits = (low > np.median(low)).flatten()
+    width = (bits.size + 3) // 4
+    return "{:0>{width}x}".format(int("".join("1" if b else "0" for b in bits), 2), width=width)
+
+
 def image_id_for(image) -> str:
-    rgb = image.convert("RGB")
-    return "img_" + hashlib.sha1(rgb.tobytes() + str(rgb.size).encode()).hexdigest()[:16]
+    """`img_<phash>` as generate_image_hash (main.py:581-585); falls back to a pixel digest without scipy."""
+    try:
+        return "img_" + phash_hex(image)
+    except ImportError:
+        rgb = image.convert("RGB")
+        return "img_" + hashlib.sha1(rgb.tobytes() + str(rgb.size).encode()).hexdigest()[:16]
 
 
 def create_app():

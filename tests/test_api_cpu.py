@@ -121,3 +121,22 @@ def test_errors_become_500_json(client):
     assert r.status_code == 500 and r.json()["success"] is False and "error" in r.json()
     r = client.post("/api/upload", files={"file": ("x.png", _png(99), "image/png")}, data={"remove_bg": "true"})
     assert r.status_code == 500
+
+
+def test_perceptual_hash_ids():
+    """`img_` + 16 hex digits as generate_image_hash (main.py:581-585): stable for the same pixels in another container,
+    different for different pictures."""
+    from PIL import Image
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.api import image_id_for
+
+    yy, xx = np.mgrid[0:120, 0:160]
+    a = np.stack([(np.sin(xx / 17.0) + np.cos(yy / 11.0)) * 60 + 128, (xx * yy / 80.0) % 255, (xx + yy) / 2.0], -1)
+    im = Image.fromarray(a.clip(0, 255).astype(np.uint8))
+    one = image_id_for(im)
+    assert one.startswith("img_") and len(one) == 4 + 16 and int(one[4:], 16) >= 0
+    buf = io.BytesIO()
+    im.save(buf, format="PNG")
+    assert image_id_for(Image.open(io.BytesIO(buf.getvalue()))) == one
+    other = Image.fromarray(np.random.Generator(np.random.Philox(3)).integers(0, 256, (120, 160, 3), dtype=np.uint8))
+    assert image_id_for(other) != one
