@@ -52,6 +52,7 @@ struct Tower {
     DevBuf xc, hc, ctxc, uc;  // compact [Bp, *] buffers of the pooled rows (last-layer pruning)
     DevBuf stats;             // [Mp][hidden/64][2] partial row (sum, sumsq) for the LayerNorm-fused GEMMs
     DevBuf xb;                // bf16 copy of the residual stream (A operand of the LayerNorm-folded GEMMs)
+    DevBuf splitk;            // f32 partial products of the split-K GEMMs (middle batch sizes), allocated on demand
     bool pooled_compact = false;
     int last_B = 0, last_T = 0;
     int64_t tap_stride = 0;  // floats per recorded tap
@@ -204,14 +205,21 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // per-GEMM tile height (fills the 256 CUs x 2 blocks evenly) and the row count padded to it
     // the LayerNorm-fused / folded GEMMs (ln_mode 1, 2) exist for the 128-column tiles only
     const bool plain = e->ln_mode == 0;
-    const int bm_qkv = plain ? gemm_pick_variant(M, 3 * d) : gemm_pick_bm(M, 3 * d);
-    const int bm_d = plain ? gemm_pick_variant(M, d) : gemm_pick_bm(M, d);
-    const int bm_mlp = plain ? gemm_pick_variant(M, tw.mlp) : gemm_pick_bm(M, tw.mlp);
+    int bm_qkv = plain ? gemm_pick_variant(M, 3 * d) : gemm_pick_bm(M, 3 * d);
+    int bm_d = plain ? gemm_pick_variant(M, d) : gemm_pick_bm(M, d);
+    int bm_mlp = plain ? gemm_pick_variant(M, tw.mlp) : gemm_pick_bm(M, tw.mlp);
+    // experiment knobs (tools/option_ab.py): force a tile variant per GEMM family
+    if (const int f = mmiss_option("gemm_bm_qkv", 0)) bm_qkv = f;
+    if (const int f = mmiss_option("gemm_bm_d", 0)) bm_d = f;
+    if (const int f = mmiss_option("gemm_bm_mlp", 0)) bm_mlp = f;
     auto padded = [&](int bm) { return (int)round_up(M, bm % 1000); };
     // 256 x 256 phase-pipelined tile for the widest GEMMs: from N = 4096 (the ViT-L/14 FC1: 336 -> 320 us inside the bs-128
     // encode, +2 % images/s; the L/14 QKV at N = 3072 and the B/32 GEMMs do not gain). Option gemm_256 = minimum N, 0 = never.
     const int min_n256 = mmiss_option("gemm_256", 4096);
     auto use256 = [&](int N) { return plain && min_n256 > 0 && N >= min_n256 && (N % 256) == 0 && (d % 64) == 0 && M > 512; };
+    // split-K scratch for the narrow long-K GEMM (FC2) while its grid is far below the CU count
+    if (gemm_splitk_candidate((int64_t)((M + 127) / 128) * (d / GEMM_BN), tw.mlp))
+        MM_TRY(tw.splitk.ensure((size_t)8 * round_up(M, 192) * d * 4));
     auto tap = [&](int which) -> int {
         if (e->record_taps && tw.taps.p)
             MM_HIP(hipMemcpyAsync(tw.taps.as<float>() + (size_t)which * tw.tap_stride, tw.x.p, (size_t)M * d * 4,
@@ -299,6 +307,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         ep.out = tw.x.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = M;
         ep.stats_out = (fuse || fold) ? tw.stats.as<float>() : nullptr;  // ... and for the next layer's LN1
         ep.xb_out = fold ? tw.xb.p : nullptr;
+        ep.splitk_ws = tw.splitk.as<float>(); ep.splitk_ws_bytes = tw.splitk.bytes;
         MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         MM_TRY(tap(l + 1));
     }
@@ -338,6 +347,10 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
                        e->cls.as<float>(), tw.pos.as<float>(), B, tw.T, d);
     GemmEpi ep{};
     ep.out = tw.x.p; ep.aux = tw.pos.as<float>(); ep.ldo = d; ep.m_valid = Mpatch; ep.p0 = e->G * e->G; ep.p1 = tw.T;
+    if (gemm_splitk_candidate((int64_t)(Mpp / (bm_p % 1000)) * (d / GEMM_BN), e->Kp)) {
+        MM_TRY(tw.splitk.ensure((size_t)8 * Mpp * d * 4));
+        ep.splitk_ws = tw.splitk.as<float>(); ep.splitk_ws_bytes = tw.splitk.bytes;
+    }
     MM_TRY(launch_gemm(st, MMISS_EPI_PATCH_F32, bm_p, e->patches.p, e->patch_w.p, ep, Mpp, d, e->Kp));
     // pre_layrnorm, in place on the fp32 residual stream (HF:modeling_clip.py:640)
     MM_TRY(launch_layernorm(st, tw.x.as<float>(), e->pre_g.as<float>(), e->pre_b.as<float>(), tw.x.p, false, nullptr,
@@ -793,6 +806,11 @@ extern "C" int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant
     MM_TRY(mmiss_use_device(device));
     GemmEpi ep{};
     ep.out = out; ep.bias = bias; ep.aux = aux; ep.ldo = N; ep.m_valid = M; ep.p0 = p0; ep.p1 = p1;
+    static DevBuf dbg_splitk;  // debug entry only: scratch so that the split-K path can be exercised
+    if ((int64_t)M * N <= (1 << 22)) {
+        MM_TRY(dbg_splitk.ensure((size_t)8 * M * N * 4));
+        ep.splitk_ws = dbg_splitk.as<float>(); ep.splitk_ws_bytes = dbg_splitk.bytes;
+    }
     if (variant == 256) return launch_gemm256(reinterpret_cast<hipStream_t>(hip_stream), epi, A, W, ep, M, N, K);
     if (variant > 1000 && variant < 2000) return launch_gemm_ring(reinterpret_cast<hipStream_t>(hip_stream), epi, variant - 1000, A, W, ep, M, N, K);
     return launch_gemm(reinterpret_cast<hipStream_t>(hip_stream), epi, variant, A, W, ep, M, N, K);

@@ -36,6 +36,9 @@ struct GemmEpi {
     // BIAS_RESID_F32: if set, partial (sum, sumsq) of the NEW residual rows, [M][N/64][2] — the next LayerNorm's input
     float* stats_out;
     void* xb_out;           // BIAS_RESID_F32: if set, bf16 copy of the new residual rows [M, ldo] (next GEMM's A operand)
+    // split-K (launch_gemm only): f32 scratch for the partial products [splits][M][N]; null = never split
+    float* splitk_ws;
+    size_t splitk_ws_bytes;
 };
 
 #define MMISS_EPI_GROUPMAX_F32 5  // internal: out f32 [M, N/16] = max over the lane's 16 n (see decode below)
@@ -261,8 +264,12 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void gemm16_kernel(con
     int bm, bn;
     tile_order(wg, nbm, nbn, ep.m_fast, bm, bn);
 
-    const IN* Ab = A + (size_t)bm * BM * K;
-    const IN* Wb = W + (size_t)bn * BN * K;
+    // split-K: gridDim.y workgroups share one output tile, each walks K / gridDim.y of the reduction (row stride stays K)
+    // and writes its f32 partial tile to slab blockIdx.y of ep.out (the caller reduces the slabs)
+    const int k_len = K / (int)gridDim.y;
+    const IN* Ab = A + (size_t)bm * BM * K + (size_t)blockIdx.y * k_len;
+    const IN* Wb = W + (size_t)bn * BN * K + (size_t)blockIdx.y * k_len;
+    if (gridDim.y > 1) ep.out = reinterpret_cast<float*>(ep.out) + (size_t)blockIdx.y * M * ep.ldo;
 
     // staging: one wave-instruction = 8 rows x 128 B; lane -> (row r_in, 16-B slot p); slot p of row r
     // holds global chunk p ^ (r & 7)
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void gemm16_kernel(con
 #pragma unroll
         for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = K / GEMM_BK;
+    const int nt = k_len / GEMM_BK;
 
     // ---- ALN: per-row (mean, rstd) from the partial sums, register staging of the f32 tile
     const int xc8 = tid & 7, xr0 = tid >> 3;
@@ -469,7 +476,8 @@ static inline int gemm_pick_variant(int64_t M_rows, int N) {
 }
 
 template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2>
-static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
+                            int splits = 1) {
     constexpr int BN = 64 * NWN;
     constexpr int LDS = 2 * (BM + BN) * 128 + (ALN ? BM * 8 : 0);
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN>), LDS));
@@ -478,7 +486,7 @@ static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const 
     GemmEpi e2 = ep;
     const int forced = mmiss_option("gemm_group_m", -1);  // experiment knob (tools/gemm_order_sweep.py)
     if (forced >= 0 && e2.m_fast != 1) e2.m_fast = forced;
-    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN>), dim3(nwg), dim3(128 * NWN), LDS, st,
+    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN>), dim3(nwg, splits), dim3(128 * NWN), LDS, st,
                        reinterpret_cast<const IN*>(A), reinterpret_cast<const IN*>(W), M, N, K, e2);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
@@ -548,6 +556,82 @@ static int launch_gemm_bm(hipStream_t st, int bm, const void* A, const void* W, 
     MM_FAIL(MMISS_ERR_ARG, "gemm: unsupported tile height %d", bm);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-K for the middle batch sizes. With 150 .. 3000 rows a narrow GEMM (out-proj / FC2: N = 768) has 12-100 tiles
+// for 256 CUs and each workgroup walks its whole K behind a barrier per 64-wide step at ~0.9 us per step (one
+// workgroup per CU: nothing hides the load latency): FC2 (K = 3072) takes 42 us at ANY batch from 3 to 32 images. So the
+// K loop is cut into `splits` slices run by different workgroups (grid.y), each writing an f32 partial tile to a scratch
+// slab, and splitk_reduce_kernel sums the slabs in a fixed order (deterministic) and applies the real epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int Mws, int N,
+                                                            GemmEpi ep) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N >> 2;
+    const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) * 4;
+    if (m >= ep.m_valid) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
+    for (int sp = 1; sp < splits; ++sp) v += *reinterpret_cast<const f32x4*>(ws + ((size_t)sp * Mws + m) * N + n);
+    if constexpr (EPI == MMISS_EPI_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n) = v;
+    } else if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + n);
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y[r] = v[r] + b[r];
+            if constexpr (EPI == MMISS_EPI_BIAS_QGELU_BF16) y[r] = quick_gelu(y[r]);
+        }
+        u32x2 pk;
+        pk[0] = pack_bf16x2(y[0], y[1]);
+        pk[1] = pack_bf16x2(y[2], y[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n) = pk;
+    } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+        v += *reinterpret_cast<const f32x4*>(ep.bias + n);
+        float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
+        *reinterpret_cast<f32x4*>(p) = *reinterpret_cast<const f32x4*>(p) + v;
+    } else {  // MMISS_EPI_PATCH_F32
+        const int img = m / ep.p0, pt = m - img * ep.p0;
+        const f32x4 pos = *reinterpret_cast<const f32x4*>(ep.aux + (size_t)(1 + pt) * ep.ldo + n);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + ((size_t)img * ep.p1 + 1 + pt) * ep.ldo + n) = v + pos;
+    }
+}
+
+// Split-K is considered for long-K GEMMs of at most this many tiles (bs-256 sweep, tools/batch_sweep.py: 228 tiles
+// gain 7 %, 300 tiles lose 3 % to the reduce traffic).
+static inline int gemm_splitk_max_tiles() { return mmiss_option("gemm_splitk_max_tiles", 256); }
+static inline bool gemm_splitk_candidate(int64_t tiles, int K) { return K >= 1536 && tiles <= gemm_splitk_max_tiles(); }
+
+// How many K slices for a tiled GEMM of `tiles` workgroups (1 = do not split).
+static inline int gemm_splitk_splits(int tiles, int K, int M, int N, const GemmEpi& ep) {
+    if (!ep.splitk_ws || ep.stats_out || ep.xb_out || mmiss_option("gemm_splitk", 1) == 0) return 1;
+    if (!gemm_splitk_candidate(tiles, K)) return 1;
+    int splits = mmiss_option("gemm_splitk_target", 384) / tiles;  // workgroups aimed at (256 CUs x up to 2)
+    if (splits < 2) splits = 2;
+    if (splits > 8) splits = 8;
+    while (splits > 1 && ((K % (splits * GEMM_BK)) != 0 || K / (splits * GEMM_BK) < 6)) --splits;
+    if (splits > 1 && (size_t)splits * M * N * 4 > ep.splitk_ws_bytes) return 1;
+    return splits;
+}
+
+template <int EPI>
+static int launch_gemm_splitk(hipStream_t st, int bm, int splits, const void* A, const void* W, const GemmEpi& ep, int M,
+                              int N, int K) {
+    GemmEpi part{};
+    part.out = ep.splitk_ws; part.ldo = N; part.m_valid = M; part.m_fast = ep.m_fast;
+    switch (bm) {
+        case 128: MM_TRY((launch_gemm_inst<__bf16, 128, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
+        case 160: MM_TRY((launch_gemm_inst<__bf16, 160, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
+        default: MM_TRY((launch_gemm_inst<__bf16, 192, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
+    }
+    const int mv = ep.m_valid < M ? ep.m_valid : M;
+    const int64_t threads = (int64_t)mv * (N / 4);
+    hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, ep.splitk_ws,
+                       splits, M, N, ep);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
 // bf16 GEMM of the CLIP towers. `bm` = tile height (128/160/192; 0 = 128); M must be a multiple of it.
 // gemm_skinny.h (included at the end of this header): the M <= 256 path
 static inline bool gemm_skinny_ok(int epi, int mv, int N, int K, const GemmEpi& ep);
@@ -577,6 +661,21 @@ static int launch_gemm(hipStream_t st, int epi, int bm, const void* A, const voi
     const int mv = ep.m_valid < M ? ep.m_valid : M;
     const double bytes = 2.0 * ((double)mv * K + (double)N * K) +
                          (double)out_elt * mv * N * (epi == MMISS_EPI_BIAS_RESID_F32 ? 2 : 1);
+    if (bm < 1000) {
+        const int splits = gemm_splitk_splits((M / bm) * (N / GEMM_BN), K, M, N, ep);
+        if (splits > 1) {
+            static const char* knames[] = {"gemm_splitk_f32", "gemm_splitk_bias", "gemm_splitk_bias_qgelu",
+                                           "gemm_splitk_bias_resid", "gemm_splitk_patch"};
+            MM_PROF(knames[epi], st, gemm_flops(mv, N, K), bytes + 8.0 * splits * (double)M * N);
+            switch (epi) {
+                case MMISS_EPI_F32: return launch_gemm_splitk<MMISS_EPI_F32>(st, bm, splits, A, W, ep, M, N, K);
+                case MMISS_EPI_BIAS_BF16: return launch_gemm_splitk<MMISS_EPI_BIAS_BF16>(st, bm, splits, A, W, ep, M, N, K);
+                case MMISS_EPI_BIAS_QGELU_BF16: return launch_gemm_splitk<MMISS_EPI_BIAS_QGELU_BF16>(st, bm, splits, A, W, ep, M, N, K);
+                case MMISS_EPI_BIAS_RESID_F32: return launch_gemm_splitk<MMISS_EPI_BIAS_RESID_F32>(st, bm, splits, A, W, ep, M, N, K);
+                default: return launch_gemm_splitk<MMISS_EPI_PATCH_F32>(st, bm, splits, A, W, ep, M, N, K);
+            }
+        }
+    }
     MM_PROF(names[epi], st, gemm_flops(mv, N, K), bytes);
     switch (epi) {
         case MMISS_EPI_F32: return launch_gemm_bm<__bf16, MMISS_EPI_F32>(st, bm, A, W, ep, M, N, K);

@@ -1,4 +1,4 @@
-// Skinny bf16 GEMM for M <= 128 rows (<= 512 when N <= 1024): C[M,N] = A[M,K] · W[N,K]^T with the encoder's epilogues.
+// Skinny bf16 GEMM for M <= 128 rows (<= 320 when N <= 1024): C[M,N] = A[M,K] · W[N,K]^T with the encoder's epilogues.
 //
 // Why: the reference serves ONE image or ONE query string per request (backend/app/utils.py:76-77,88-97), i.e.
 // M = 50 or <= 77 token rows per GEMM, and the pruned last layer / the projection head run on M = batch rows. The
@@ -102,13 +102,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
 }
 
 // Whether launch_gemm should take the skinny path for `mv` valid rows.
-// Whether launch_gemm should take the skinny path for `mv` valid rows: up to 128 rows always, up to 512 rows when the
-// output is narrow (N <= 1024: out-proj / FC2 / projection head, where the tiled kernel has only 12-32 workgroups;
+// Whether launch_gemm should take the skinny path for `mv` valid rows: up to 128 rows always, up to 320 rows when the
+// output is narrow (N <= 1024: out-proj / FC2 / projection head, where the tiled kernel has only 12-24 workgroups;
 // ViT-L/14 at one image = 257 rows: out-proj 9.5 vs 15.1 us, FC2 28 vs 48 us, but QKV / FC1 18-23 vs 12-13 us).
+// Above that the tiled kernel takes over, with split-K for the long-K GEMM (whole encode at 400 rows: 0.88 vs 0.94 ms).
 static inline bool gemm_skinny_ok(int epi, int mv, int N, int K, const GemmEpi& ep) {
     if (mmiss_option("gemm_skinny", 1) == 0) return false;
     const int forced = mmiss_option("gemm_skinny_max_m", 0);
-    const int max_m = forced > 0 ? forced : (N <= 1024 ? 512 : 128);
+    const int max_m = forced > 0 ? forced : (N <= 1024 ? 320 : 128);
     return mv >= 1 && mv <= max_m && (N % 16) == 0 && (K % 128) == 0 && epi >= 0 && epi <= 4 && !ep.stats_out &&
            !ep.xb_out;
 }

@@ -96,11 +96,13 @@ def test_gemm_256_tile_pipeline(env, M, N, K):
     # bit-identical to the 128-row kernel: same per-element k order
     o128 = torch.zeros(M, N, device="cuda")
     o256 = torch.zeros(M, N, device="cuda")
-    _lib.set_option("gemm_skinny", 0)  # M = 256 would otherwise take the weight-streaming kernel
+    _lib.set_option("gemm_skinny", 0)  # M = 256 would otherwise take the weight-streaming kernel ...
+    _lib.set_option("gemm_splitk", 0)  # ... or, with few tiles and a long K, the split-K path
     try:
         _gemm(env, _lib.EPI_F32, A, W, o128, bm=128)
     finally:
         _lib.set_option("gemm_skinny", 1)
+        _lib.set_option("gemm_splitk", 1)
     _gemm(env, _lib.EPI_F32, A, W, o256, bm=256)
     assert torch.equal(o128, o256)
 
@@ -123,10 +125,12 @@ def test_gemm_ring_pipeline(env, bm, M, N, K):
     if K % 64 == 0:
         base = torch.zeros(M, N, device="cuda")
         _lib.set_option("gemm_skinny", 0)  # small M would otherwise take the weight-streaming kernel
+        _lib.set_option("gemm_splitk", 0)
         try:
             _gemm(env, _lib.EPI_F32, A, W, base, bm=bm)
         finally:
             _lib.set_option("gemm_skinny", 1)
+            _lib.set_option("gemm_splitk", 1)
         assert torch.equal(out, base)
     x0 = torch.randn(M, N, device="cuda", generator=g)
     x = x0.clone()
@@ -153,10 +157,12 @@ def test_gemm_wide_tile(env, bm, M, N, K):
     assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
     base = torch.zeros(M, N, device="cuda")
     _lib.set_option("gemm_skinny", 0)
+    _lib.set_option("gemm_splitk", 0)
     try:
         _gemm(env, _lib.EPI_F32, A, W, base, bm=bm)
     finally:
         _lib.set_option("gemm_skinny", 1)
+        _lib.set_option("gemm_splitk", 1)
     assert torch.equal(out, base)
     ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
     _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, ob, bias=bias, bm=2000 + bm)
@@ -166,6 +172,43 @@ def test_gemm_wide_tile(env, bm, M, N, K):
     x = x0.clone()
     _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias, bm=2000 + bm)
     assert torch.allclose(x, x0 + ref + bias, rtol=1e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 768, 3072), (1280, 768, 3072), (256, 256, 1536), (640, 1024, 4096)])
+def test_gemm_split_k(env, M, N, K):
+    """Few tiles and a long K: the K loop is cut into slices run by different workgroups (partials in scratch, summed
+    in a fixed order by a second kernel that applies the epilogue). Same restatement, same tolerances; repeatable bits."""
+    torch, _lib, lib = env
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = A.float() @ W.float().T
+    _lib.set_option("gemm_skinny", 0)  # keep the tiled kernel in charge of these row counts
+    try:
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _gemm(env, _lib.EPI_F32, A, W, out, bm=128)
+        assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+        again = torch.zeros(M, N, device="cuda")
+        _gemm(env, _lib.EPI_F32, A, W, again, bm=128)
+        assert torch.equal(out, again)
+        _lib.set_option("gemm_splitk", 0)
+        whole = torch.zeros(M, N, device="cuda")
+        _gemm(env, _lib.EPI_F32, A, W, whole, bm=128)
+        _lib.set_option("gemm_splitk", 1)
+        assert not torch.equal(out, whole)  # the split path really ran (different summation order) ...
+        assert (out - whole).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())  # ... and agrees
+        x0 = torch.randn(M, N, device="cuda", generator=g)
+        x = x0.clone()
+        _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias, bm=128)
+        assert torch.allclose(x, x0 + ref + bias, rtol=1e-5, atol=3e-4)
+        ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, ob, bias=bias, bm=128)
+        r2 = ref + bias
+        assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
+    finally:
+        _lib.set_option("gemm_skinny", 1)
+        _lib.set_option("gemm_splitk", 1)
 
 
 def test_gemm_asymmetric_layout(env):

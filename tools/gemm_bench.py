@@ -21,7 +21,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "l14":  # ViT-L/14: 257 tokens per image
               ("L14 fc1", _lib.EPI_BIAS_QGELU_BF16, 4096, 1024), ("L14 fc2", _lib.EPI_BIAS_RESID_F32, 1024, 4096)]
 res = []
 for name, epi, N, K in shapes:
-    for bm in (128, 160, 192, 256, 2128, 2160, 2192):
+    for bm in (128, 160, 192, 256, 1128, 1160, 1192, 2128, 2160, 2192):
         if (bm == 256 or bm > 2000) and N % 256:
             continue
         tile = bm % 1000
