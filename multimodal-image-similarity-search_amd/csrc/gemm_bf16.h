@@ -244,13 +244,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
 // B=256) and its kernel boundary; the W tile keeps its LDS-DMA path.
 // NWN = waves along n (2: BM x 128 tile, 4 waves, two workgroups per CU; 4: BM x 256 tile, 8 waves, one workgroup per CU:
 // the A panel is staged once for 256 output columns instead of once per 128).
-template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2>
-__global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void gemm16_kernel(const IN* __restrict__ A,
+// S3 = three staging buffers (prefetch distance 2 K-tiles, one workgroup per CU): for grids below the CU count, where a
+// CU holds a single workgroup and nothing else hides the load latency of the two-buffer loop (0.55-0.66 us per K-tile
+// measured against 0.27 us of MFMA work, tools/gemm_midm_ksweep.py).
+template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2, bool S3 = false>
+__global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_kernel(const IN* __restrict__ A,
                                                                              const IN* __restrict__ W, int M, int N, int K,
                                                                              GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename MfmaIn<IN>::frag frag;
     static_assert(NWN == 2 || (NWN == 4 && !ALN), "wide tiles have no fused-LayerNorm staging");
+    static_assert(!S3 || (NWN == 2 && !ALN), "the three-buffer loop exists for the plain 128-column tile");
     constexpr int BN = 64 * NWN, NWAVES = 2 * NWN;
     constexpr int JT = BM / 32;               // 16-row m sub-tiles per wave (wave tile = BM/2 x 64)
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
@@ -361,6 +365,46 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void gemm16_kernel(con
         }
         x_load(0);
     }
+    auto mma_tile = [&](int buf) {
+        const char* sA = smem + buf * BUF;
+        const char* sW = sA + A_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            frag wf[4], af[JT];
+            const int chunk = 4 * s + fg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wn * 64 + i * 16 + fr;
+                wf[i] = *reinterpret_cast<const frag*>(sW + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int row = wm * (BM / 2) + j * 16 + fr;
+                af[j] = *reinterpret_cast<const frag*>(sA + row * 128 + ((chunk ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < JT; ++j) acc[i][j] = MfmaIn<IN>::mma(wf[i], af[j], acc[i][j]);
+        }
+    };
+    if constexpr (S3) {
+        // K-tile t lives in buffer t % 3; its loads were issued two steps earlier. A wave issues LPS loads per stage, so
+        // "at most LPS outstanding" means stage t has landed while stage t+1 may still fly.
+        constexpr int LPS = BM / 32 + 4;
+        stage(0, 0);
+        if (nt > 1) stage(1, 1);
+        int buf = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // every wave's stage-t loads are in LDS; every wave is done reading buffer (t-1) % 3
+            if (t + 2 < nt) stage(buf == 0 ? 2 : buf - 1, t + 2);
+            mma_tile(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        __syncthreads();  // the epilogue reuses the staging buffers as transpose patches
+    } else {
     stage(0, 0);
     if constexpr (ALN) x_write(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -399,6 +443,7 @@ __global__ __launch_bounds__(128 * NWN, NWN == 2 ? 2 : 1) void gemm16_kernel(con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    }  // two-buffer loop
 
     // acc[i][j][reg] = C[m = m_base + j*16][n = n_base + i*16 + reg]
     const int m_base = bm * BM + wm * (BM / 2) + fr;
@@ -475,18 +520,18 @@ static inline int gemm_pick_variant(int64_t M_rows, int N) {
     return best;
 }
 
-template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2>
+template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2, bool S3 = false>
 static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
                             int splits = 1) {
     constexpr int BN = 64 * NWN;
-    constexpr int LDS = 2 * (BM + BN) * 128 + (ALN ? BM * 8 : 0);
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN>), LDS));
+    constexpr int LDS = (S3 ? 3 : 2) * (BM + BN) * 128 + (ALN ? BM * 8 : 0);
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN, S3>), LDS));
     if (N % BN) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: N=%d is not a multiple of the %d-column tile", N, BN);
     const int nwg = (M / BM) * (N / BN);
     GemmEpi e2 = ep;
     const int forced = mmiss_option("gemm_group_m", -1);  // experiment knob (tools/gemm_order_sweep.py)
     if (forced >= 0 && e2.m_fast != 1) e2.m_fast = forced;
-    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN>), dim3(nwg, splits), dim3(128 * NWN), LDS, st,
+    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN, S3>), dim3(nwg, splits), dim3(128 * NWN), LDS, st,
                        reinterpret_cast<const IN*>(A), reinterpret_cast<const IN*>(W), M, N, K, e2);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
@@ -542,12 +587,23 @@ static int launch_gemm_ln(hipStream_t st, int epi, int bm, const float* X, const
     MM_FAIL(MMISS_ERR_ARG, "gemm_ln: unsupported tile height %d", bm);
 }
 
+// Two or three staging buffers: a grid of at most 256 workgroups puts one workgroup on a CU whatever its LDS footprint,
+// so the deeper pipeline costs no occupancy there and hides the load latency the second workgroup would have hidden.
+template <typename IN, int BM, int EPI>
+static int launch_gemm_stages(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
+                              int splits = 1) {
+    const int64_t wgs = (int64_t)(M / BM) * (N / GEMM_BN) * splits;
+    if (wgs <= 256 && K / splits >= 4 * GEMM_BK && mmiss_option("gemm_s3", 1) != 0)
+        return launch_gemm_inst<IN, BM, EPI, false, 2, true>(st, A, W, ep, M, N, K, splits);
+    return launch_gemm_inst<IN, BM, EPI>(st, A, W, ep, M, N, K, splits);
+}
+
 template <typename IN, int EPI>
 static int launch_gemm_bm(hipStream_t st, int bm, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
     switch (bm) {
-        case 128: return launch_gemm_inst<IN, 128, EPI>(st, A, W, ep, M, N, K);
-        case 160: return launch_gemm_inst<IN, 160, EPI>(st, A, W, ep, M, N, K);
-        case 192: return launch_gemm_inst<IN, 192, EPI>(st, A, W, ep, M, N, K);
+        case 128: return launch_gemm_stages<IN, 128, EPI>(st, A, W, ep, M, N, K);
+        case 160: return launch_gemm_stages<IN, 160, EPI>(st, A, W, ep, M, N, K);
+        case 192: return launch_gemm_stages<IN, 192, EPI>(st, A, W, ep, M, N, K);
         // 2000 + BM: the BM x 256 tile with 8 waves (one workgroup per CU)
         case 2128: return launch_gemm_inst<IN, 128, EPI, false, 4>(st, A, W, ep, M, N, K);
         case 2160: return launch_gemm_inst<IN, 160, EPI, false, 4>(st, A, W, ep, M, N, K);
@@ -620,9 +676,9 @@ static int launch_gemm_splitk(hipStream_t st, int bm, int splits, const void* A,
     GemmEpi part{};
     part.out = ep.splitk_ws; part.ldo = N; part.m_valid = M; part.m_fast = ep.m_fast;
     switch (bm) {
-        case 128: MM_TRY((launch_gemm_inst<__bf16, 128, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
-        case 160: MM_TRY((launch_gemm_inst<__bf16, 160, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
-        default: MM_TRY((launch_gemm_inst<__bf16, 192, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
+        case 128: MM_TRY((launch_gemm_stages<__bf16, 128, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
+        case 160: MM_TRY((launch_gemm_stages<__bf16, 160, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
+        default: MM_TRY((launch_gemm_stages<__bf16, 192, MMISS_EPI_F32>(st, A, W, part, M, N, K, splits))); break;
     }
     const int mv = ep.m_valid < M ? ep.m_valid : M;
     const int64_t threads = (int64_t)mv * (N / 4);
