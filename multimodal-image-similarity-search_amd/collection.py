@@ -67,25 +67,39 @@ class FlatCollection:
     def _meta_path(self):
         return os.path.join(self._persist_dir, f"{self.name}.meta.json")
 
-    def _index_path(self):
-        return os.path.join(self._persist_dir, f"{self.name}.index.mmiss")
+    def _index_path(self, gen: int = 0):
+        """Generation 0 is the legacy single-file name; later generations carry their number, and the metadata file
+        names the generation it belongs to - so replacing the metadata file is the one atomic switch of a save."""
+        suffix = "" if gen == 0 else f".{gen}"
+        return os.path.join(self._persist_dir, f"{self.name}.index{suffix}.mmiss")
 
     def persist(self) -> None:
         if not self._persist_dir:
             return
         with self._lock:
+            old_gen = getattr(self, "_index_gen", 0)
+            new_gen = old_gen + 1 if self._index is not None else old_gen
             blob = {
                 "name": self.name, "metadata": self.metadata, "dim": self._dim, "dtype": self._dtype,
                 "next_label": self._next_label, "ids": self._ids, "labels": self._labels,
                 "metadatas": [self._meta.get(l) for l in self._labels],
                 "documents": [self._docs.get(l) for l in self._labels],
+                "index_gen": new_gen,
             }
             tmp = self._meta_path() + ".tmp"
             with open(tmp, "w") as f:
                 json.dump(blob, f)
+                f.flush()
+                os.fsync(f.fileno())
             if self._index is not None:
-                self._index.save(self._index_path())
-            os.replace(tmp, self._meta_path())
+                self._index.save(self._index_path(new_gen))   # a new file: the previous generation stays intact
+            os.replace(tmp, self._meta_path())                 # the atomic switch
+            self._index_gen = new_gen
+            if new_gen != old_gen:
+                try:
+                    os.remove(self._index_path(old_gen))
+                except FileNotFoundError:
+                    pass
 
     def _load(self) -> None:
         with open(self._meta_path()) as f:
@@ -99,9 +113,10 @@ class FlatCollection:
         self._by_id = dict(zip(self._ids, self._labels))
         self._meta = dict(zip(self._labels, blob["metadatas"]))
         self._docs = dict(zip(self._labels, blob["documents"]))
+        self._index_gen = int(blob.get("index_gen", 0))
         if self._dim is not None and self._labels:
             self._ensure_index(self._dim)
-            self._index.load(self._index_path())
+            self._index.load(self._index_path(self._index_gen))
             if self._index.count() != len(self._labels):
                 raise RuntimeError("collection files are inconsistent (row count differs from id count)")
 
@@ -296,7 +311,7 @@ class PersistentClient:
 
     def delete_collection(self, name: str) -> None:
         self._open.pop(name, None)
-        for suffix in (".meta.json", ".index.mmiss"):
-            p = os.path.join(self.path, name + suffix)
-            if os.path.exists(p):
-                os.remove(p)
+        for fn in os.listdir(self.path):   # the metadata file and every index generation of this collection
+            if fn == name + ".meta.json" or fn == name + ".meta.json.tmp" or (
+                    fn.startswith(name + ".index") and fn.endswith(".mmiss")):
+                os.remove(os.path.join(self.path, fn))
