@@ -247,16 +247,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
 // S3 = three staging buffers (prefetch distance 2 K-tiles, one workgroup per CU): for grids below the CU count, where a
 // CU holds a single workgroup and nothing else hides the load latency of the two-buffer loop (0.55-0.66 us per K-tile
 // measured against 0.27 us of MFMA work, tools/gemm_midm_ksweep.py).
-template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2, bool S3 = false>
-__global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_kernel(const IN* __restrict__ A,
+// NWM = waves along m (2, or 4 for the 8-wave form of the 128-column tile: two waves per SIMD inside ONE workgroup, for
+// grids below the CU count where no second workgroup shares the CU to overlap a wave's LDS-DMA issue and barrier waits).
+template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2, bool S3 = false, int NWM = 2>
+__global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 : 1) void gemm16_kernel(const IN* __restrict__ A,
                                                                              const IN* __restrict__ W, int M, int N, int K,
                                                                              GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename MfmaIn<IN>::frag frag;
     static_assert(NWN == 2 || (NWN == 4 && !ALN), "wide tiles have no fused-LayerNorm staging");
     static_assert(!S3 || (NWN == 2 && !ALN), "the three-buffer loop exists for the plain 128-column tile");
-    constexpr int BN = 64 * NWN, NWAVES = 2 * NWN;
-    constexpr int JT = BM / 32;               // 16-row m sub-tiles per wave (wave tile = BM/2 x 64)
+    static_assert(NWM == 2 || (NWM == 4 && NWN == 2 && !ALN && BM % 64 == 0), "8-wave form: 128-column tile, BM % 64 == 0");
+    constexpr int BN = 64 * NWN, NWAVES = NWM * NWN;
+    constexpr int JT = BM / (16 * NWM);       // 16-row m sub-tiles per wave (wave tile = BM/NWM x 64)
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
     constexpr int RPT = BM / 32;              // ALN: rows per thread (thread t: 16-byte chunk t&7 of rows (t>>3) + 32 i)
     const int tid = threadIdx.x;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_k
         char* sA = smem + buf * BUF;
         char* sW = sA + A_BYTES;
         const size_t koff = (size_t)kt * GEMM_BK + src_chunk;
-        if constexpr (!ALN && NWN == 2) {
+        if constexpr (!ALN && NWN == 2 && NWM == 2) {
 #pragma unroll
             for (int i = 0; i < BM / 32; ++i) {
                 const int rowblk = wave * (BM / 32) + i;
@@ -297,8 +300,8 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_k
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rowblk = wave * 4 + i;
+        for (int i = 0; i < BN / 8 / NWAVES; ++i) {
+            const int rowblk = wave * (BN / 8 / NWAVES) + i;
             glds16(Wb + (size_t)(rowblk * 8 + r_in) * K + koff, sW + rowblk * 1024);
         }
     };
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_k
             }
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                const int row = wm * (BM / 2) + j * 16 + fr;
+                const int row = wm * (BM / NWM) + j * 16 + fr;
                 af[j] = *reinterpret_cast<const frag*>(sA + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_k
     if constexpr (S3) {
         // K-tile t lives in buffer t % 3; its loads were issued two steps earlier. A wave issues LPS loads per stage, so
         // "at most LPS outstanding" means stage t has landed while stage t+1 may still fly.
-        constexpr int LPS = BM / 32 + 4;
+        constexpr int LPS = (BM / 8 + NWAVES - 1) / NWAVES + BN / 8 / NWAVES;  // pieces a wave issues per stage
+        static_assert(NWM == 2 || (BM / 8) % NWAVES == 0, "counted waits need the same piece count on every wave");
         stage(0, 0);
         if (nt > 1) stage(1, 1);
         int buf = 0;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_k
             }
 #pragma unroll
             for (int j = 0; j < JT; ++j) {
-                const int row = wm * (BM / 2) + j * 16 + fr;
+                const int row = wm * (BM / NWM) + j * 16 + fr;
                 af[j] = *reinterpret_cast<const frag*>(sA + row * 128 + ((chunk ^ (row & 7)) << 4));
             }
 #pragma unroll
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_k
     }  // two-buffer loop
 
     // acc[i][j][reg] = C[m = m_base + j*16][n = n_base + i*16 + reg]
-    const int m_base = bm * BM + wm * (BM / 2) + fr;
+    const int m_base = bm * BM + wm * (BM / NWM) + fr;
     const int n_base = bn * BN + wn * 64 + 4 * fg;
 
     if constexpr (EPI == MMISS_EPI_GROUPMAX_F32) {
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(128 * NWN, (NWN == 2 && !S3) ? 2 : 1) void gemm16_k
     }
 
     // all waves are past the loop's last barrier: the staging buffers are dead, each wave takes a private patch
-    gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / 2), bn * BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
+    gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / NWM), bn * BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
                            smem + NWAVES * EPI_PATCH_BYTES + wave * (JT * 16 * 8));
 }
 
@@ -520,18 +524,18 @@ static inline int gemm_pick_variant(int64_t M_rows, int N) {
     return best;
 }
 
-template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2, bool S3 = false>
+template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2, bool S3 = false, int NWM = 2>
 static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
                             int splits = 1) {
     constexpr int BN = 64 * NWN;
     constexpr int LDS = (S3 ? 3 : 2) * (BM + BN) * 128 + (ALN ? BM * 8 : 0);
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN, S3>), LDS));
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm16_kernel<IN, BM, EPI, ALN, NWN, S3, NWM>), LDS));
     if (N % BN) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: N=%d is not a multiple of the %d-column tile", N, BN);
     const int nwg = (M / BM) * (N / BN);
     GemmEpi e2 = ep;
     const int forced = mmiss_option("gemm_group_m", -1);  // experiment knob (tools/gemm_order_sweep.py)
     if (forced >= 0 && e2.m_fast != 1) e2.m_fast = forced;
-    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN, S3>), dim3(nwg, splits), dim3(128 * NWN), LDS, st,
+    hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN, S3, NWM>), dim3(nwg, splits), dim3(64 * NWN * NWM), LDS, st,
                        reinterpret_cast<const IN*>(A), reinterpret_cast<const IN*>(W), M, N, K, e2);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
@@ -593,8 +597,12 @@ template <typename IN, int BM, int EPI>
 static int launch_gemm_stages(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
                               int splits = 1) {
     const int64_t wgs = (int64_t)(M / BM) * (N / GEMM_BN) * splits;
-    if (wgs <= 256 && K / splits >= 4 * GEMM_BK && mmiss_option("gemm_s3", 1) != 0)
+    if (wgs <= 256 && K / splits >= 4 * GEMM_BK && mmiss_option("gemm_s3", 1) != 0) {
+        if constexpr (BM == 128) {
+            if (mmiss_option("gemm_w8", 1) != 0) return launch_gemm_inst<IN, BM, EPI, false, 2, true, 4>(st, A, W, ep, M, N, K, splits);
+        }
         return launch_gemm_inst<IN, BM, EPI, false, 2, true>(st, A, W, ep, M, N, K, splits);
+    }
     return launch_gemm_inst<IN, BM, EPI>(st, A, W, ep, M, N, K, splits);
 }
 
