@@ -603,6 +603,11 @@ static int launch_gemm_stages(hipStream_t st, const void* A, const void* W, cons
         }
         return launch_gemm_inst<IN, BM, EPI, false, 2, true>(st, A, W, ep, M, N, K, splits);
     }
+    if constexpr (BM == 128) {
+        // the 8-wave form (two buffers) also while the grid is at most one round of 2 workgroups per CU, where many CUs
+        // still hold a single workgroup (bs 128: 2.10 -> 2.03 ms, bs 192: 2.60 -> 2.55 ms per encode)
+        if (wgs <= mmiss_option("gemm_w8_max_wgs", 512)) return launch_gemm_inst<IN, BM, EPI, false, 2, false, 4>(st, A, W, ep, M, N, K, splits);
+    }
     return launch_gemm_inst<IN, BM, EPI>(st, A, W, ep, M, N, K, splits);
 }
 
