@@ -12,6 +12,8 @@ from mmiss_amd.encoder import VIT_B32, ClipEncoder, random_state_dict  # noqa: E
 
 enc = ClipEncoder(VIT_B32, device=0, max_batch_image=256, max_batch_text=8)
 enc.load_state_dict(random_state_dict(VIT_B32, seed=0))
+if os.environ.get("MMISS_LN_MODE"):
+    enc.set_fuse_ln(int(os.environ["MMISS_LN_MODE"]))  # 0 separate LayerNorm kernels, 1 operand-fused, 2 folded
 for B in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256):
     x = torch.randn(B, 3, 224, 224, device="cuda")
     out = torch.empty(B, 512, device="cuda")
