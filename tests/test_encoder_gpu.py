@@ -215,6 +215,26 @@ def test_b32_image_and_text_embeddings(b32):
     assert (1 - _cos(out_t, ref_t)).max() < COS_TOL
 
 
+def test_b32_every_gemm_regime_agrees_with_the_oracle(b32):
+    """The same 16 images at batch 1 (weight-streaming GEMMs), 5 (skinny for the narrow outputs, tiled for the wide
+    ones), and 16 (800 rows: three-buffer 8-wave tiles, split-K FC2 and patch embedding): every regime within the
+    north_star tolerance of the oracle and of each other."""
+    enc, W, co = b32
+    s = co.VIT_B32
+    rng = np.random.Generator(np.random.Philox(31))
+    px = rng.standard_normal((16, 3, 224, 224), dtype=np.float32)
+    ref = co.embed_images(px, W, s)
+    whole = enc.encode_image(px)
+    assert (1 - _cos(whole, ref)).max() < COS_TOL
+    fives = np.concatenate([enc.encode_image(px[i:i + 5]) for i in range(0, 16, 5)])
+    ones = np.concatenate([enc.encode_image(px[i:i + 1]) for i in range(16)])
+    for other in (fives, ones):
+        assert (1 - _cos(other, ref)).max() < COS_TOL
+        assert (1 - _cos(other, whole)).max() < 2e-5  # only the summation order of the GEMMs differs
+    again = enc.encode_image(px)
+    np.testing.assert_array_equal(whole, again)  # every path is deterministic (fixed-order split-K reduction)
+
+
 def test_longclip_l14_geometry_two_layers():
     """The reference HEAD's model family (ViT-L/14 towers, 248-token text table, 768-d joint space; utils.py:16-17)
     with the depth cut to 2 layers to keep the oracle fast: d=1024/16 heads/T=257 vision, d=768/12 heads/T=248 text."""
