@@ -321,13 +321,20 @@ def main():
         torch.cuda.synchronize()  # rank 0 only: no barrier here
         rz = {k["kernel"]: k["ms"] / k["launches"] for k in _lib.prof_read() if k["kernel"].startswith("resize")}
         _lib.prof_enable(False)
-        raw_host = raw.cpu().numpy().reshape(-1)
+        # host buffers: 4 chunks of B images, so that the library's copy/compute pipeline has something to overlap
+        NH = 4 * B
+        raw_host = np.tile(raw.cpu().numpy().reshape(-1), 4)
+        offs_h = np.arange(NH, dtype=np.int64) * (IH * IW * 3)
+        hs_h, ws_h = np.full(NH, IH, np.int32), np.full(NH, IW, np.int32)
+        enc.encode_image_rgb_packed(raw_host, offs_h, hs_h, ws_h)
         t0 = time.perf_counter()
-        for _ in range(3):
-            enc.encode_image_rgb_packed(raw_host, offs, hs, ws)
-        hdt = (time.perf_counter() - t0) / 3
+        for _ in range(2):
+            enc.encode_image_rgb_packed(raw_host, offs_h, hs_h, ws_h)
+        hdt = (time.perf_counter() - t0) / 2 / 4
         rz_ms = rz.get("resize_crop", 0.0)
         ingest = {"images_per_s_device_resident": round(B / idt, 1), "images_per_s_host_buffers": round(B / hdt, 1),
+                  "host_buffers": f"{NH} images per call in pageable host memory, chunks of {B}: the next chunk is copied while the "
+                                  "current one is computed",
                   "batch": B, "source": f"{IW}x{IH} RGB8", "resize_crop_kernel_ms": round(rz_ms, 4),
                   "resize_coeffs_kernel_ms": round(rz.get("resize_coeffs", 0.0), 4),
                   "resize_crop_gbs": round((B * IH * IW * 3 + B * 224 * 224 * 3) / (rz_ms * 1e-3) / 1e9, 1) if rz_ms else None,

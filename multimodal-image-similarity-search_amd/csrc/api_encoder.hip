@@ -99,6 +99,11 @@ struct mmiss_encoder {
     DevBuf pix_stage; // host->device staging of pixels
     // raw-RGB input (N2): source blob staging, per-image descriptors, fixed-point taps, windows, uint8 crops
     DevBuf raw_stage, rz_desc, rz_pool, rz_bounds, crop_stage;
+    // host inputs larger than one chunk are pipelined: the next chunk's bytes cross PCIe on copy_stream into the second
+    // staging buffer while the current chunk is computed (ev_copied / ev_free order the two streams)
+    DevBuf stage2[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     ResizeDesc* rz_host = nullptr;   // pinned; rz_copied marks the end of its last host->device copy
     size_t rz_host_cap = 0;
     hipEvent_t rz_copied = nullptr;
@@ -386,8 +391,10 @@ int finish_call(mmiss_encoder* e, hipStream_t st, bool must_sync) {
 
 
 // Resize + centre-crop images b0 .. b0+nb-1 of a raw RGB8 blob into dst_dev (uint8 [nb,S,S,3], device), on st.
+// `staged` != null: the chunk's byte range [its lo, its hi) of the host blob already sits at `staged` in HBM.
 int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb_bytes, const int64_t* offsets,
-                 const int32_t* heights, const int32_t* widths, int b0, int nb, uint8_t* dst_dev, hipStream_t st) {
+                 const int32_t* heights, const int32_t* widths, int b0, int nb, uint8_t* dst_dev, hipStream_t st,
+                 const uint8_t* staged = nullptr) {
     const int S = e->cfg.v_image;
     if (!e->rz_copied) MM_HIP(hipEventCreateWithFlags(&e->rz_copied, hipEventDisableTiming));
     else MM_HIP(hipEventSynchronize(e->rz_copied));  // the previous call's descriptor upload has left the buffer
@@ -421,7 +428,10 @@ int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb
         hi = off + bytes > hi ? off + bytes : hi;
     }
     const uint8_t* src = rgb;
-    if (!rgb_dev) {  // stage the byte range this chunk touches
+    if (staged) {
+        for (int i = 0; i < nb; ++i) e->rz_host[i].src_off -= lo;
+        src = staged;
+    } else if (!rgb_dev) {  // stage the byte range this chunk touches
         MM_TRY(e->raw_stage.ensure((size_t)(hi - lo)));
         MM_HIP(hipMemcpyAsync(e->raw_stage.p, rgb + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
         for (int i = 0; i < nb; ++i) e->rz_host[i].src_off -= lo;
@@ -440,7 +450,7 @@ int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb
     }
     {
         MM_PROF("resize_crop", st, 0.0, (double)(hi - lo) + (double)nb * S * S * 3);
-        launch_resize_crop(st, max_ksx, src, rgb_dev ? rgb_bytes : hi - lo, e->rz_desc.as<ResizeDesc>(), e->rz_pool.as<int32_t>(),
+        launch_resize_crop(st, max_ksx, src, (rgb_dev && !staged) ? rgb_bytes : hi - lo, e->rz_desc.as<ResizeDesc>(), e->rz_pool.as<int32_t>(),
                            e->rz_bounds.as<int32_t>(), dst_dev, S, nb);
         MM_HIP(hipGetLastError());
     }
@@ -527,6 +537,11 @@ extern "C" int mmiss_encoder_destroy(mmiss_encoder* enc) {
     (void)hipDeviceSynchronize();
     if (enc->own_stream) (void)hipStreamDestroy(enc->own_stream);
     if (enc->rz_copied) (void)hipEventDestroy(enc->rz_copied);
+    if (enc->copy_stream) (void)hipStreamDestroy(enc->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (enc->ev_copied[i]) (void)hipEventDestroy(enc->ev_copied[i]);
+        if (enc->ev_free[i]) (void)hipEventDestroy(enc->ev_free[i]);
+    }
     if (enc->rz_host) (void)hipHostFree(enc->rz_host);
     delete enc;
     return MMISS_OK;
@@ -619,6 +634,30 @@ extern "C" int mmiss_encoder_finalize(mmiss_encoder* enc) {
     return MMISS_OK;
 }
 
+// streams / events of the host-input pipeline, created on first use
+static int ensure_pipeline(mmiss_encoder* enc) {
+    if (!enc->copy_stream) MM_HIP(hipStreamCreateWithFlags(&enc->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!enc->ev_copied[i]) MM_HIP(hipEventCreateWithFlags(&enc->ev_copied[i], hipEventDisableTiming));
+        if (!enc->ev_free[i]) MM_HIP(hipEventCreateWithFlags(&enc->ev_free[i], hipEventDisableTiming));
+    }
+    return MMISS_OK;
+}
+
+// byte range [lo, hi) of the host blob touched by images b0 .. b0+nb-1 (validated again by resize_chunk)
+static void rgb_chunk_range(const int64_t* offsets, const int32_t* heights, const int32_t* widths, int b0, int nb,
+                            int64_t rgb_bytes, int64_t& lo, int64_t& hi) {
+    lo = INT64_MAX; hi = 0;
+    for (int i = b0; i < b0 + nb; ++i) {
+        const int64_t off = offsets[i], end = off + (int64_t)heights[i] * widths[i] * 3;
+        lo = off < lo ? off : lo;
+        hi = end > hi ? end : hi;
+    }
+    if (lo < 0) lo = 0;
+    if (hi > rgb_bytes) hi = rgb_bytes;
+    if (hi < lo) hi = lo;
+}
+
 static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8, int32_t B, float* out) {
     if (!enc || !pixels || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_encode_image: null argument");
     if (B < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_encode_image: B = %d", B);
@@ -635,16 +674,39 @@ static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8
     }
     const bool in_dev = mmiss_is_device_ptr(pixels), out_dev = mmiss_is_device_ptr(out);
     const size_t img_bytes = (size_t)3 * S * S * (src_u8 ? 1 : 4);
-    if (!in_dev) MM_TRY(enc->pix_stage.ensure(img_bytes * maxb));
-    for (int b0 = 0; b0 < B; b0 += maxb) {
+    // host pixels, several chunks: chunk k+1 crosses PCIe on copy_stream while chunk k is computed (see encode_rgb_impl)
+    const bool piped = !in_dev && B > maxb;
+    if (piped) {
+        MM_TRY(ensure_pipeline(enc));
+        MM_TRY(enc->stage2[0].ensure(img_bytes * maxb));
+        MM_TRY(enc->stage2[1].ensure(img_bytes * maxb));
+        MM_HIP(hipMemcpyAsync(enc->stage2[0].p, pixels, img_bytes * maxb, hipMemcpyHostToDevice, enc->copy_stream));
+        MM_HIP(hipEventRecord(enc->ev_copied[0], enc->copy_stream));
+    } else if (!in_dev) {
+        MM_TRY(enc->pix_stage.ensure(img_bytes * maxb));
+    }
+    for (int b0 = 0, k = 0; b0 < B; b0 += maxb, ++k) {
         const int nb = (B - b0 < maxb) ? B - b0 : maxb;
         const char* src = reinterpret_cast<const char*>(pixels) + (size_t)b0 * img_bytes;
-        if (!in_dev) {
+        if (piped) {
+            MM_HIP(hipStreamWaitEvent(st, enc->ev_copied[k & 1], 0));
+            src = enc->stage2[k & 1].as<char>();
+        } else if (!in_dev) {
             MM_HIP(hipMemcpyAsync(enc->pix_stage.p, src, img_bytes * nb, hipMemcpyHostToDevice, st));
             src = enc->pix_stage.as<char>();
         }
         float* dst = out_dev ? out + (size_t)b0 * P : enc->vis.out_stage.as<float>();
         MM_TRY(encode_image_chunk(enc, src, src_u8, nb, dst, st));
+        if (piped) {
+            MM_HIP(hipEventRecord(enc->ev_free[k & 1], st));  // (recorded after the whole chunk; im2col is its only reader)
+            if (b0 + maxb < B) {
+                const int nxt = (k + 1) & 1, b1 = b0 + maxb, n1 = (B - b1 < maxb) ? B - b1 : maxb;
+                if (k >= 1) MM_HIP(hipStreamWaitEvent(enc->copy_stream, enc->ev_free[nxt], 0));
+                MM_HIP(hipMemcpyAsync(enc->stage2[nxt].p, reinterpret_cast<const char*>(pixels) + (size_t)b1 * img_bytes,
+                                      img_bytes * n1, hipMemcpyHostToDevice, enc->copy_stream));
+                MM_HIP(hipEventRecord(enc->ev_copied[nxt], enc->copy_stream));
+            }
+        }
         if (!out_dev) {
             MM_HIP(hipMemcpyAsync(out + (size_t)b0 * P, dst, (size_t)nb * P * 4, hipMemcpyDeviceToHost, st));
             MM_HIP(hipStreamSynchronize(st));
@@ -652,6 +714,7 @@ static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8
             MM_HIP(hipStreamSynchronize(st));  // the staging buffer is reused by the next chunk
         }
     }
+    if (piped) MM_HIP(hipStreamSynchronize(enc->copy_stream));
     return finish_call(enc, st, !out_dev);
 }
 
@@ -686,21 +749,59 @@ static int encode_rgb_impl(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_b
     const bool out_dev = mmiss_is_device_ptr(out_emb ? (const void*)out_emb : (const void*)out_u8);
     const size_t crop_bytes = (size_t)3 * S * S;
     MM_TRY(enc->crop_stage.ensure(crop_bytes * maxb));
-    for (int b0 = 0; b0 < B; b0 += maxb) {
+    // host blob, several chunks: chunk k+1 crosses PCIe (copy_stream -> stage2[(k+1)&1]) while chunk k is computed
+    const bool piped = !in_dev && B > maxb;
+    if (piped) {
+        MM_TRY(ensure_pipeline(enc));
+        int64_t need = 0;
+        for (int b0 = 0; b0 < B; b0 += maxb) {
+            int64_t lo, hi;
+            rgb_chunk_range(offsets, heights, widths, b0, (B - b0 < maxb) ? B - b0 : maxb, rgb_bytes, lo, hi);
+            need = hi - lo > need ? hi - lo : need;
+        }
+        MM_TRY(enc->stage2[0].ensure((size_t)need + 4));
+        MM_TRY(enc->stage2[1].ensure((size_t)need + 4));
+        int64_t lo, hi;
+        rgb_chunk_range(offsets, heights, widths, 0, maxb, rgb_bytes, lo, hi);
+        MM_HIP(hipMemcpyAsync(enc->stage2[0].p, rgb + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, enc->copy_stream));
+        MM_HIP(hipEventRecord(enc->ev_copied[0], enc->copy_stream));
+    }
+    for (int b0 = 0, k = 0; b0 < B; b0 += maxb, ++k) {
         const int nb = (B - b0 < maxb) ? B - b0 : maxb;
         uint8_t* crops = (out_u8 && out_dev) ? out_u8 + crop_bytes * b0 : enc->crop_stage.as<uint8_t>();
-        MM_TRY(resize_chunk(enc, rgb, in_dev, rgb_bytes, offsets, heights, widths, b0, nb, crops, st));
+        if (piped) {
+            const int cur = k & 1;
+            MM_HIP(hipStreamWaitEvent(st, enc->ev_copied[cur], 0));
+            MM_TRY(resize_chunk(enc, rgb, true, rgb_bytes, offsets, heights, widths, b0, nb, crops, st,
+                                enc->stage2[cur].as<uint8_t>()));
+            MM_HIP(hipEventRecord(enc->ev_free[cur], st));  // the resize has consumed the staged bytes
+        } else {
+            MM_TRY(resize_chunk(enc, rgb, in_dev, rgb_bytes, offsets, heights, widths, b0, nb, crops, st));
+        }
         if (out_u8 && !out_dev) {
             MM_HIP(hipMemcpyAsync(out_u8 + crop_bytes * b0, crops, crop_bytes * nb, hipMemcpyDeviceToHost, st));
         }
         if (out_emb) {
             float* dst = out_dev ? out_emb + (size_t)b0 * P : enc->vis.out_stage.as<float>();
             MM_TRY(encode_image_chunk(enc, crops, true, nb, dst, st));
-            if (!out_dev) MM_HIP(hipMemcpyAsync(out_emb + (size_t)b0 * P, dst, (size_t)nb * P * 4, hipMemcpyDeviceToHost, st));
+        }
+        if (piped && b0 + maxb < B) {
+            // chunk k is enqueued: now move chunk k+1 (a pageable-memory copy blocks this thread, not the GPU)
+            const int nxt = (k + 1) & 1, b1 = b0 + maxb;
+            int64_t lo, hi;
+            rgb_chunk_range(offsets, heights, widths, b1, (B - b1 < maxb) ? B - b1 : maxb, rgb_bytes, lo, hi);
+            if (k >= 1) MM_HIP(hipStreamWaitEvent(enc->copy_stream, enc->ev_free[nxt], 0));
+            MM_HIP(hipMemcpyAsync(enc->stage2[nxt].p, rgb + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, enc->copy_stream));
+            MM_HIP(hipEventRecord(enc->ev_copied[nxt], enc->copy_stream));
+        }
+        if (out_emb && !out_dev) {
+            float* dst = enc->vis.out_stage.as<float>();
+            MM_HIP(hipMemcpyAsync(out_emb + (size_t)b0 * P, dst, (size_t)nb * P * 4, hipMemcpyDeviceToHost, st));
         }
         // staging buffers (source bytes, descriptors, crops, output) are reused by the next chunk
         if (b0 + maxb < B || !out_dev || !in_dev) MM_HIP(hipStreamSynchronize(st));
     }
+    if (piped) MM_HIP(hipStreamSynchronize(enc->copy_stream));
     return finish_call(enc, st, !out_dev);
 }
 
