@@ -47,8 +47,8 @@ int mmiss_dbg_gemm_time(int device, int epi, int variant, const void* A, const v
 /* record the residual stream after every layer during encode calls (for mmiss_encoder_tap 0..L) */
 struct mmiss_encoder;
 int mmiss_dbg_encoder_record_taps(struct mmiss_encoder* enc, int on);
-/* how LayerNorm1/2 reach the QKV / FC1 GEMMs: 0 separate LayerNorm kernels, 1 normalised during operand staging,
- * 2 (default) folded algebraically into weights + epilogue (A/B and parity tests) */
+/* how LayerNorm1/2 reach the QKV / FC1 GEMMs: -1 (default) automatic by rows per call, 0 separate LayerNorm kernels,
+ * 1 normalised during operand staging, 2 folded algebraically into weights + epilogue (A/B and parity tests) */
 int mmiss_dbg_encoder_set_fuse_ln(struct mmiss_encoder* enc, int on);
 
 /* experiment: full GEMM vs two half-M GEMMs (same stream / two streams); ms[3] per GEMM-equivalent */

@@ -84,10 +84,14 @@ struct mmiss_encoder {
     //     18-24 column blocks re-normalises its rows through registers, 342-371 TF);
     //   2 folded algebraically: A = bf16(x) written by the residual epilogues, gamma folded into the weights, the
     //     (mean, rstd) correction applied in the GEMM epilogue — no LayerNorm pass at all. Same precision
-    //     (1-cos 5e-6 either way), and at B=256 the same speed: the 2 x 13.8 us LayerNorm passes it removes per layer
-    //     come back as +9 / +4 / 2 x +6 us in the FC1 / QKV / residual epilogues (profiles/gemm_variants_r01.md).
-    // Default: 0, the simplest of three equally fast ways.
-    int ln_mode = 0;
+    //     (1-cos 5e-6 either way). With the f32 residual rows stored non-temporally (they would push the bf16 copy the
+    //     next GEMM reads out of the L2) it is 2-3 % faster than 0 from ~6000 rows up (bs 128 / 192 / 256: 1.95 vs 2.02,
+    //     2.46 vs 2.53, 3.19 vs 3.25 ms, tools/ln_mode_ab.py) and slower below (bs 64: 1.39 vs 1.33 ms), where the
+    //     weight-streaming and split-K paths it cannot feed are worth more.
+    //     Hidden size 1024 (ViT-L/14) loses 4 % with it (16 partial statistics per row in the epilogues, and FC1 gives up
+    //     its 256 x 256 tile): 4.54 vs 4.74 k images/s.
+    // -1 (default) = automatic: 2 from `ln_fold_min_rows` (6000) rows per call when hidden <= 768, else 0.
+    int ln_mode = -1;
 
     Tower vis, txt;
     // vision-only
@@ -209,7 +213,12 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     const float eps = e->cfg.ln_eps;
     // per-GEMM tile height (fills the 256 CUs x 2 blocks evenly) and the row count padded to it
     // the LayerNorm-fused / folded GEMMs (ln_mode 1, 2) exist for the 128-column tiles only
-    const bool plain = e->ln_mode == 0;
+    int mode = e->ln_mode;
+    if (mode < 0) {
+        const int forced = mmiss_option("ln_mode", -1);
+        mode = forced >= 0 ? forced : ((M >= mmiss_option("ln_fold_min_rows", 6000) && d <= 768) ? 2 : 0);
+    }
+    const bool plain = mode == 0;
     int bm_qkv = plain ? gemm_pick_variant(M, 3 * d) : gemm_pick_bm(M, 3 * d);
     int bm_d = plain ? gemm_pick_variant(M, d) : gemm_pick_bm(M, d);
     int bm_mlp = plain ? gemm_pick_variant(M, tw.mlp) : gemm_pick_bm(M, tw.mlp);
@@ -237,7 +246,6 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // rows only (compacted). Kept off while taps are recorded so the tests can compare every row of every layer.
     const bool prune = !e->record_taps;
     tw.pooled_compact = false;
-    const int mode = e->ln_mode;
     const bool fuse = mode == 1, fold = mode == 2;
     const int parts = d / 64;
     if (fuse || fold) {
@@ -850,7 +858,7 @@ extern "C" int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t
 extern "C" int mmiss_dbg_encoder_set_fuse_ln(mmiss_encoder* enc, int on) {
     if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
     std::lock_guard<std::mutex> lk(enc->mu);
-    enc->ln_mode = on < 0 ? 0 : (on > 2 ? 2 : on);  // 0 separate kernels, 1 operand-fused, 2 folded (default)
+    enc->ln_mode = on < 0 ? -1 : (on > 2 ? 2 : on);  // -1 automatic, 0 separate kernels, 1 operand-fused, 2 folded
     return MMISS_OK;
 }
 

@@ -27,6 +27,7 @@ struct GemmEpi {
     int m_valid;        // rows >= m_valid are not stored
     int p0, p1;         // PATCH: p0 = patches per image (G), p1 = tokens per image (T). GROUPMAX: p0 = valid n
     int m_fast;         // block order: 0 = n fastest (blocks sharing an A panel adjacent), 1 = m fastest
+    int nt_out;         // bit 0: store the f32 residual rows non-temporally; bit 1: the bf16 outputs too
     // LayerNorm fused into the A operand (ALN kernels: A is the f32 residual stream, normalised while it is staged)
     const float* ln_stats;  // [M][ln_parts][2] partial (sum, sum of squares) of every row
     const float* ln_g;      // gamma [K]
@@ -190,8 +191,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
             const int m = m_wave + j * 16 + row;
             if constexpr (OUT_BF16) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 144 + rchunk * 16);
-                if (m < ep.m_valid)
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_wave + rchunk * 8) = v;
+                if (m < ep.m_valid) {
+                    u32x4* po = reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_wave + rchunk * 8);
+                    if (ep.nt_out & 2) __builtin_nontemporal_store(v, po);
+                    else *po = v;
+                }
             } else {
                 float rs = 0.f, rq = 0.f;  // this lane's share of the row's (sum, sumsq) over the wave's 64 columns
 #pragma unroll
@@ -204,7 +208,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
                         } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
                             float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
                             v = *reinterpret_cast<const f32x4*>(p) + v;
-                            *reinterpret_cast<f32x4*>(p) = v;
+                            // folded-LayerNorm mode: the next kernel reads the bf16 copy, not the f32 stream, so the f32 rows
+                            // are stored non-temporally and leave the L2 to the bf16 rows
+                            if (ep.xb_out || (ep.nt_out & 1)) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+                            else *reinterpret_cast<f32x4*>(p) = v;
                             if (ep.xb_out) {
                                 u32x2 pk;
                                 pk[0] = pack_bf16x2(v[0], v[1]);
@@ -535,6 +542,7 @@ static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const 
     GemmEpi e2 = ep;
     const int forced = mmiss_option("gemm_group_m", -1);  // experiment knob (tools/gemm_order_sweep.py)
     if (forced >= 0 && e2.m_fast != 1) e2.m_fast = forced;
+    e2.nt_out |= mmiss_option("gemm_nt", 0);
     hipLaunchKernelGGL((gemm16_kernel<IN, BM, EPI, ALN, NWN, S3, NWM>), dim3(nwg, splits), dim3(64 * NWN * NWM), LDS, st,
                        reinterpret_cast<const IN*>(A), reinterpret_cast<const IN*>(W), M, N, K, e2);
     MM_HIP(hipGetLastError());

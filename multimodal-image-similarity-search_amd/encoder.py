@@ -287,8 +287,9 @@ class ClipEncoder:
     def record_taps(self, on: bool = True):
         _lib.check(self._lib.mmiss_dbg_encoder_record_taps(self._h, 1 if on else 0))
 
-    def set_fuse_ln(self, mode=2):
-        """0 = separate LayerNorm kernels, 1 = normalise during operand staging, 2 = folded (default)."""
+    def set_fuse_ln(self, mode=-1):
+        """-1 = automatic (folded from ~6000 rows per call, separate below; the default), 0 = separate LayerNorm kernels,
+        1 = normalise during operand staging, 2 = folded into the GEMMs."""
         _lib.check(self._lib.mmiss_dbg_encoder_set_fuse_ln(self._h, int(mode)))
 
     def tap(self, tower: int, what: int, n: int) -> np.ndarray:

@@ -11,7 +11,7 @@ from mmiss_amd.encoder import VIT_B32, ClipEncoder, random_state_dict  # noqa: E
 
 enc = ClipEncoder(VIT_B32, device=0, max_batch_image=256, max_batch_text=8)
 enc.load_state_dict(random_state_dict(VIT_B32, seed=0))
-for B in (256, 192, 128):
+for B in (256, 192, 128, 96, 64):
     x = torch.randn(B, 3, 224, 224, device="cuda")
     out = torch.empty(B, 512, device="cuda")
     res = {0: [], 2: []}

@@ -19,6 +19,8 @@ CLASSES = {
     "gemm_bf16_bias_resid": r"gemm16_kernelIDF16bLi160ELi3E",
     "gemm_bf16_bias_resid_pruned": r"gemm16_kernelIDF16bLi128ELi3E",
     "gemm_bf16_bias_qgelu": r"gemm16_kernelIDF16bLi192ELi2E",
+    "gemm_bf16_lnfold_qgelu": r"gemm16_kernelIDF16bLi192ELi8E",
+    "gemm_bf16_lnfold_bias": r"gemm16_kernelIDF16bLi192ELi7E",
     "gemm_bf16_bias": r"gemm16_kernelIDF16bLi192ELi1E",
     "gemm_bf16_patch": r"gemm16_kernelIDF16bLi160ELi4E",
     "score_gemm_f16": r"gemm256_kernelIDF16_Li5E",
@@ -28,7 +30,10 @@ CLASSES = {
     "im2col": r"im2col_kernel<",
 }
 ALGORITHMIC = {  # bytes per launch the kernel must move, averaged over the shapes in the class
-    "gemm_bf16_bias_resid": 130.7e6, "gemm_bf16_bias_qgelu": 103.0e6, "gemm_bf16_bias": 82.2e6,
+    # residual GEMM in the folded-LayerNorm mode (the default from 6000 rows): 130.7 MB of GEMM traffic + the bf16 copy of
+    # the new residual rows (19.7 MB) + their partial LayerNorm statistics (1.2 MB) that replace the LayerNorm pass
+    "gemm_bf16_bias_resid": 151.6e6, "gemm_bf16_bias_qgelu": 103.0e6, "gemm_bf16_bias": 82.2e6,
+    "gemm_bf16_lnfold_qgelu": 104.3e6, "gemm_bf16_lnfold_bias": 83.5e6,
     "scan_topk_f16": 10.24e9,
 }
 
