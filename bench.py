@@ -395,6 +395,8 @@ def main():
                        "index_dtype": "f16", "k": K_TOP, "parallelism": f"dp{world}",
                        "flops_per_image": 8.818e9, "flops_per_image_executed": 8.298e9,
                        "pruning": "last layer: out-proj + MLP on the pooled (CLS) rows only",
+                       "layernorm": "folded into the QKV / FC1 GEMMs (automatic from 6000 rows per call): the residual GEMM's "
+                                    "epilogue also writes the bf16 copy and the row statistics of the new residual rows",
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),
