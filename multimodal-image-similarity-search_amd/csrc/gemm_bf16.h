@@ -116,8 +116,10 @@ template <> struct MfmaIn<_Float16> {
 #define EPI_PATCH_BYTES (16 * 272)  // per wave: 16 rows x (64 f32 + 16 B pad); bf16 rows use 144 B of it
 
 template <int EPI, int JT>
+// stat_part / stat_parts (folded LayerNorm only): the stat_parts waves that share these rows (same wm) share ONE stat_area
+// and each finalises 1/stat_parts of the rows' statistics; a workgroup barrier publishes them (all waves call the epilogue).
 __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4][JT], int m_wave, int n_wave, char* patch,
-                                              int lane, char* stat_area = nullptr) {
+                                              int lane, char* stat_area = nullptr, int stat_part = 0, int stat_parts = 1) {
     const int fr = lane & 15, fg = lane >> 4;
     const int rrow = lane >> 3, rchunk = lane & 7;  // read-back role: row (of 8) and 16-byte chunk (of 8)
     constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
@@ -133,7 +135,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
         for (int i = 0; i < 4; ++i) cvec[i] = *reinterpret_cast<const f32x4*>(ep.aux + n_wave + i * 16 + 4 * fg);
         // per-row (mean, rstd) of this wave's JT*16 rows from the partial sums, kept in LDS next to the patch
         sstat = reinterpret_cast<float*>(stat_area);
-        for (int r = lane; r < JT * 16; r += 64) {
+        const int per = (JT * 16 + stat_parts - 1) / stat_parts;
+        const int r_end = (stat_part + 1) * per < JT * 16 ? (stat_part + 1) * per : JT * 16;
+        for (int r = stat_part * per + lane; r < r_end; r += 64) {
             // the row's partial sums are contiguous (parts x (sum, sumsq)); vector loads, all issued before the adds
             const f32x4* st = reinterpret_cast<const f32x4*>(ep.ln_stats + (size_t)(m_wave + r) * ep.ln_parts * 2);
             const int n4 = ep.ln_parts >> 1;  // hidden % 128 == 0 -> parts is even
@@ -149,9 +153,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
             sstat[2 * r] = mean;
             sstat[2 * r + 1] = 1.0f / sqrtf(var + ep.ln_eps);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (stat_parts > 1) {
+            __syncthreads();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
@@ -480,8 +488,9 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
     }
 
     // all waves are past the loop's last barrier: the staging buffers are dead, each wave takes a private patch
+    // folded LayerNorm: the NWN waves of one wm share their rows' statistics (one area per wm, each wave finalises a share)
     gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / NWM), bn * BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
-                           smem + NWAVES * EPI_PATCH_BYTES + wave * (JT * 16 * 8));
+                           smem + NWAVES * EPI_PATCH_BYTES + wm * (JT * 16 * 8), wn, NWN);
 }
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
