@@ -429,7 +429,8 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         MM_HIP(hipMemsetAsync(ix->cand.p, 0xff, (size_t)Q * ncand * 4, st));  // all -1
     } else if (dense) {
         // the pad rows up to the tile multiple are readable (capacity is a multiple of 1024) and masked in the epilogue
-        const bool big = Q > 128;  // 256x256 phase-pipelined tile once there are two 128-query tiles to share a row panel
+        // 256x256 phase-pipelined tile once there are two 128-query tiles to share a row panel
+        const bool big = Q >= mmiss_option("score_big_min_q", 129);
         const int64_t Npad = round_up(N, big ? 256 : 128);
         const int Mq = (int)round_up(Q, big ? 256 : 128);
         const int ng = (int)(Npad / 16);
