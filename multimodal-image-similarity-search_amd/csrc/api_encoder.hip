@@ -233,7 +233,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     auto use256 = [&](int N) { return plain && min_n256 > 0 && N >= min_n256 && (N % 256) == 0 && (d % 64) == 0 && M > 512; };
     // split-K scratch for the narrow long-K GEMM (FC2) while its grid is far below the CU count
     if (gemm_splitk_candidate((int64_t)((M + 127) / 128) * (d / GEMM_BN), tw.mlp))
-        MM_TRY(tw.splitk.ensure((size_t)8 * round_up(M, 192) * d * 4));
+        MM_TRY(tw.splitk.ensure((size_t)8 * (round_up(M, 128) + 192) * d * 4));  // any tile height's row padding
     auto tap = [&](int which) -> int {
         if (e->record_taps && tw.taps.p)
             MM_HIP(hipMemcpyAsync(tw.taps.as<float>() + (size_t)which * tw.tap_stride, tw.x.p, (size_t)M * d * 4,
