@@ -244,7 +244,7 @@ def main():
 
     # ---------------------------------------------------------------- the reference's own regime: one request at a time
     latency = None
-    if rank == 0 and not args.no_text:
+    if rank == 0 and world == 1 and not args.no_text:  # single-GPU diagnostics; at N > 1 rank 0 must not lag the others
         one_px = pixels[:1].contiguous()
         one_emb = torch.empty(1, D, device=dev)
 
@@ -299,7 +299,7 @@ def main():
 
     # ---------------------------------------------------------------- ingest: raw RGB uploads -> embeddings
     ingest = None
-    if rank == 0 and not args.no_text:
+    if rank == 0 and world == 1 and not args.no_text:  # single-GPU diagnostics; at N > 1 rank 0 must not lag the others
         IH, IW = 480, 640
         raw = torch.randint(0, 256, (B, IH, IW, 3), dtype=torch.uint8, device=dev)
         offs = np.arange(B, dtype=np.int64) * (IH * IW * 3)
