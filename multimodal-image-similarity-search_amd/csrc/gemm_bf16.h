@@ -115,11 +115,29 @@ template <> struct MfmaIn<_Float16> {
 // ------------------------------------------------------------------------------------------------
 #define EPI_PATCH_BYTES (16 * 272)  // per wave: 16 rows x (64 f32 + 16 B pad); bf16 rows use 144 B of it
 
+// (mean, rstd) of one row from its partial (sum, sum of squares) per 64 columns; the partial sums are contiguous, loaded as
+// vectors and all issued before the adds
+__device__ __forceinline__ void ln_row_stats(const GemmEpi& ep, int64_t row, float& mean, float& rstd) {
+    const f32x4* st = reinterpret_cast<const f32x4*>(ep.ln_stats + (size_t)row * ep.ln_parts * 2);
+    const int n4 = ep.ln_parts >> 1;  // hidden % 128 == 0 -> parts is even
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 buf[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) buf[q] = (q < n4) ? st[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s1 += buf[q][0] + buf[q][2]; s2 += buf[q][1] + buf[q][3]; }
+    const float kd = (float)(ep.ln_parts * 64);
+    mean = s1 / kd;
+    const float var = fmaxf(s2 / kd - mean * mean, 0.f);
+    rstd = 1.0f / sqrtf(var + ep.ln_eps);
+}
+
 template <int EPI, int JT>
 // stat_part / stat_parts (folded LayerNorm only): the stat_parts waves that share these rows (same wm) share ONE stat_area
 // and each finalises 1/stat_parts of the rows' statistics; a workgroup barrier publishes them (all waves call the epilogue).
 __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4][JT], int m_wave, int n_wave, char* patch,
-                                              int lane, char* stat_area = nullptr, int stat_part = 0, int stat_parts = 1) {
+                                              int lane, char* stat_area = nullptr, int stat_part = 0, int stat_parts = 1,
+                                              const float* pre_stats = nullptr) {
     const int fr = lane & 15, fg = lane >> 4;
     const int rrow = lane >> 3, rchunk = lane & 7;  // read-back role: row (of 8) and 16-byte chunk (of 8)
     constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
@@ -137,21 +155,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
         sstat = reinterpret_cast<float*>(stat_area);
         const int per = (JT * 16 + stat_parts - 1) / stat_parts;
         const int r_end = (stat_part + 1) * per < JT * 16 ? (stat_part + 1) * per : JT * 16;
-        for (int r = stat_part * per + lane; r < r_end; r += 64) {
-            // the row's partial sums are contiguous (parts x (sum, sumsq)); vector loads, all issued before the adds
-            const f32x4* st = reinterpret_cast<const f32x4*>(ep.ln_stats + (size_t)(m_wave + r) * ep.ln_parts * 2);
-            const int n4 = ep.ln_parts >> 1;  // hidden % 128 == 0 -> parts is even
-            float s1 = 0.f, s2 = 0.f;
-            f32x4 buf[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) buf[q] = (q < n4) ? st[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { s1 += buf[q][0] + buf[q][2]; s2 += buf[q][1] + buf[q][3]; }
-            const float kd = (float)(ep.ln_parts * 64);
-            const float mean = s1 / kd;
-            const float var = fmaxf(s2 / kd - mean * mean, 0.f);
-            sstat[2 * r] = mean;
-            sstat[2 * r + 1] = 1.0f / sqrtf(var + ep.ln_eps);
+        if (pre_stats) {  // computed before the K loop (their load latency hidden behind it): lane -> row stat_part*per + lane
+            const int r = stat_part * per + lane;
+            if (lane < per && r < r_end) { sstat[2 * r] = pre_stats[0]; sstat[2 * r + 1] = pre_stats[1]; }
+        } else {
+            for (int r = stat_part * per + lane; r < r_end; r += 64) {
+                float mean, rstd;
+                ln_row_stats(ep, (int64_t)m_wave + r, mean, rstd);
+                sstat[2 * r] = mean;
+                sstat[2 * r + 1] = rstd;
+            }
         }
         if (stat_parts > 1) {
             __syncthreads();
@@ -331,6 +344,17 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
 
     const int nt = k_len / GEMM_BK;
 
+    // ---- folded LayerNorm: this wave's share of its rows' (mean, rstd), fetched now so that the loads fly during the K loop
+    constexpr bool FOLD_EPI = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
+    float pre_stats[2] = {0.f, 1.f};
+    constexpr int STAT_PER = (JT * 16 + NWN - 1) / NWN;  // rows per sharing wave (<= 64 for every tile height)
+    if constexpr (FOLD_EPI) {
+        static_assert(STAT_PER <= 64, "one row per lane");
+        const int r = (wave % NWN) * STAT_PER + lane;
+        if (lane < STAT_PER && r < JT * 16)
+            ln_row_stats(ep, (int64_t)bm * BM + (wave / NWN) * (BM / NWM) + r, pre_stats[0], pre_stats[1]);
+    }
+
     // ---- ALN: per-row (mean, rstd) from the partial sums, register staging of the f32 tile
     const int xc8 = tid & 7, xr0 = tid >> 3;
     float ln_mean[RPT], ln_rstd[RPT];
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
     // all waves are past the loop's last barrier: the staging buffers are dead, each wave takes a private patch
     // folded LayerNorm: the NWN waves of one wm share their rows' statistics (one area per wm, each wave finalises a share)
     gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / NWM), bn * BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
-                           smem + NWAVES * EPI_PATCH_BYTES + wm * (JT * 16 * 8), wn, NWN);
+                           smem + NWAVES * EPI_PATCH_BYTES + wm * (JT * 16 * 8), wn, NWN, FOLD_EPI ? pre_stats : nullptr);
 }
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
