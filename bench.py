@@ -2,7 +2,8 @@
 """bench.py — throughput of the embed-and-retrieve hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or
+     plainly as above — then this file starts the N ranks itself as fresh child processes and relays rank 0's line)
 
 Workload (BASELINE.json configs[1]): CLIP ViT-B/32 image encode at batch 256 on synthetic, already
 CLIP-normalised 224x224 pixels resident in HBM, random-init weights (seed 0), each embedding then queried
@@ -11,7 +12,7 @@ patchify -> 12 layers -> pool -> project -> L2-normalise -> index query; `value`
 
 N > 1 (weak scaling, one process per GPU, RCCL): every rank encodes its own 256 images (no collective),
 holds its own 100k-row shard (labels are global), all-gathers the [256,512] embeddings so every rank
-searches all N*256 queries in its shard, all-gathers the per-shard top-10 and merges (X1).
+searches all N*256 queries in its shard, exchanges the per-shard top-10 in ONE packed all-gather and merges (X1).
 
 Second half of BASELINE.json's metric, reported in the same JSON line under "retrieval": cosine top-10
 over a 10M x 512 fp16 index (row-sharded over the ranks) at Q=1 (HBM-bound scan) and Q=1024.
@@ -60,8 +61,29 @@ def parse_args():
     return ap.parse_args()
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: start the N ranks as FRESH child
+    processes (python -m torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line and
+    the exit code. This parent never imports torch and never touches the GPU (a process that has initialised HIP must
+    not be replaced or forked into ranks)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, cwd=ROOT)
+    return proc.returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -69,10 +91,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+    args.gpus = world  # under torch.distributed.run the launcher's world size is the truth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     local_rank = local_rank % torch.cuda.device_count()  # (the gloo dry run puts several ranks on one GPU)
@@ -104,6 +123,7 @@ def main():
     from mmiss_amd import _lib
     from mmiss_amd.encoder import ClipEncoder, VIT_B32, random_state_dict
     from mmiss_amd.index import FlatIndex, merge_topk
+    from mmiss_amd.sharded import exchange_topk
 
     B, D, K_TOP = args.batch, VIT_B32.proj_dim, 10
     W = random_state_dict(VIT_B32, seed=0)
@@ -122,13 +142,10 @@ def main():
     def step():
         enc.encode_image(pixels, out=emb)
         if world > 1:
-            all_gather(emb_all, emb)
+            all_gather(emb_all, emb)                     # queries: every rank searches all N*256 embeddings in its shard
             lab, dst, _ = index.query(emb_all, K_TOP)
-            lab_all = torch.empty((world * lab.shape[0], lab.shape[1]), dtype=lab.dtype, device=dev)
-            dst_all = torch.empty((world * dst.shape[0], dst.shape[1]), dtype=dst.dtype, device=dev)
-            all_gather(lab_all, lab)
-            all_gather(dst_all, dst)
-            return merge_topk(dst_all.view(world, *dst.shape), lab_all.view(world, *lab.shape))
+            lab_all, dst_all = exchange_topk(lab, dst, world, all_gather=all_gather)  # X1: ONE packed all-gather
+            return merge_topk(dst_all, lab_all)
         return index.query(emb, K_TOP)
 
     def fence():
@@ -217,7 +234,7 @@ def main():
     retrieval = None
     if args.retrieval_rows > 0:
         retrieval = bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib,
-                                    all_gather, all_reduce_max)
+                                    all_gather, all_reduce_max, exchange_topk)
 
     # ---------------------------------------------------------------- text tower (BASELINE configs[2] inputs), informational
     text = None
@@ -408,7 +425,7 @@ def main():
 
 
 def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatIndex, merge_topk, _lib, all_gather,
-                    all_reduce_max):
+                    all_reduce_max, exchange_topk):
     """cosine top-10 over N x 512 f16 rows sharded over the ranks; Q=1 (HBM-bound) and Q=1024."""
     N, D, K_TOP = args.retrieval_rows, 512, 10
     per = N // world
@@ -425,11 +442,8 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
         def run():
             lab, dst, _ = idx.query(q, K_TOP)
             if world > 1:
-                lab_all = torch.empty((world * lab.shape[0], lab.shape[1]), dtype=lab.dtype, device=dev)
-                dst_all = torch.empty((world * dst.shape[0], dst.shape[1]), dtype=dst.dtype, device=dev)
-                all_gather(lab_all, lab)
-                all_gather(dst_all, dst)
-                return merge_topk(dst_all.view(world, *dst.shape), lab_all.view(world, *lab.shape))
+                lab_all, dst_all = exchange_topk(lab, dst, world, all_gather=all_gather)
+                return merge_topk(dst_all, lab_all)
             return lab, dst
 
         run()

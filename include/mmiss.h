@@ -200,8 +200,10 @@ int mmiss_blend(int device, void* hip_stream, const float* img, const float* txt
 /*
  * Merge S per-shard result lists (as produced by mmiss_index_query on each shard, then all-gathered)
  * into the global top-k: dist float32 [S,Q,k], labels int64 [S,Q,k] -> out [Q,k], ordered by
- * (distance asc, label asc), label -1 entries ignored. No reference analogue (the reference is
- * single-process); this is the one exchange step of the row-sharded index.
+ * (distance asc, label asc), label -1 entries ignored. Any S >= 1 and k <= 4096: up to 8192 entries per query are
+ * merged in one pass (8 shards x the UI's "All" = 1000 hits, backend/app/main.py:757), more in several levels.
+ * No reference analogue (the reference is single-process); this is the one exchange step of the row-sharded
+ * index.
  */
 int mmiss_merge_topk(int device, void* hip_stream, const float* dist, const int64_t* labels,
                      int32_t S, int32_t Q, int32_t k, float* out_dist, int64_t* out_labels, int32_t* out_count);

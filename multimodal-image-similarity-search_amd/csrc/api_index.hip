@@ -631,16 +631,29 @@ extern "C" int mmiss_blend(int device, void* hip_stream, const float* img, const
     return MMISS_OK;
 }
 
+// one merge level: S lists of k per query -> one list of k (S * k <= 8192 entries sorted in LDS)
+static int launch_shard_merge(hipStream_t st, const float* dd, const int64_t* dl, int S, int Q, int k, float* dod,
+                              int64_t* dol, int32_t* doc) {
+    int npow = 1;
+    while (npow < S * k) npow <<= 1;
+    const int lds = npow * 12 + 16;
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&shard_merge_kernel), lds));
+    MM_PROF("shard_merge", st, 0.0, (double)S * Q * k * 12);
+    hipLaunchKernelGGL(shard_merge_kernel, dim3(Q), dim3(256), lds, st, dd, dl, S, Q, k, dod, dol, doc);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
 extern "C" int mmiss_merge_topk(int device, void* hip_stream, const float* dist, const int64_t* labels, int32_t S,
                                 int32_t Q, int32_t k, float* out_dist, int64_t* out_labels, int32_t* out_count) {
     if (!dist || !labels || !out_dist || !out_labels) MM_FAIL(MMISS_ERR_ARG, "mmiss_merge_topk: null argument");
-    if (S <= 0 || Q < 0 || k <= 0 || (int64_t)S * k > 4096)
-        MM_FAIL(MMISS_ERR_ARG, "mmiss_merge_topk: S=%d Q=%d k=%d (S*k must be <= 4096)", S, Q, k);
+    if (S <= 0 || Q < 0 || k <= 0 || k > 4096)
+        MM_FAIL(MMISS_ERR_ARG, "mmiss_merge_topk: S=%d Q=%d k=%d (need S > 0, 0 < k <= 4096)", S, Q, k);
     if (Q == 0) return MMISS_OK;
     MM_TRY(mmiss_use_device(device));
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
     const size_t n_in = (size_t)S * Q * k, n_out = (size_t)Q * k;
-    DevBuf bd, bl, bod, bol, boc;
+    DevBuf bd, bl, bod, bol, boc, td[2], tl[2];
     const float* dd = dist; const int64_t* dl = labels;
     float* dod = out_dist; int64_t* dol = out_labels; int32_t* doc = out_count;
     if (!mmiss_is_device_ptr(dist)) { MM_TRY(bd.alloc(n_in * 4)); MM_HIP(hipMemcpyAsync(bd.p, dist, n_in * 4, hipMemcpyHostToDevice, st)); dd = bd.as<float>(); }
@@ -650,18 +663,30 @@ extern "C" int mmiss_merge_topk(int device, void* hip_stream, const float* dist,
         MM_TRY(bod.alloc(n_out * 4)); MM_TRY(bol.alloc(n_out * 8)); MM_TRY(boc.alloc((size_t)Q * 4));
         dod = bod.as<float>(); dol = bol.as<int64_t>(); doc = boc.as<int32_t>();
     }
-    int npow = 1;
-    while (npow < S * k) npow <<= 1;
-    {
-        MM_PROF("shard_merge", st, 0.0, (double)n_in * 12);
-        hipLaunchKernelGGL(shard_merge_kernel, dim3(Q), dim3(256), npow * 12 + 16, st, dd, dl, S, Q, k, dod, dol, doc);
-        MM_HIP(hipGetLastError());
+    // The reference's "All" search asks for 1000 hits (main.py:757): 8 shards x 1000 = 8000 entries sort in one 96 KB LDS
+    // pass. Beyond 8192 entries the lists are merged in groups of G = 8192 / k lists per level (a top-k of top-k's is
+    // the top-k), each level S -> ceil(S / G) lists, until one is left.
+    const int G = 8192 / k;  // >= 2 because k <= 4096
+    int cur_S = S, flip = 0;
+    while (cur_S > G) {
+        const int nxt = (cur_S + G - 1) / G;
+        MM_TRY(td[flip].ensure((size_t)nxt * n_out * 4));
+        MM_TRY(tl[flip].ensure((size_t)nxt * n_out * 8));
+        for (int g = 0; g < nxt; ++g) {
+            const int s0 = g * G, sn = std::min(G, cur_S - s0);
+            MM_TRY(launch_shard_merge(st, dd + (size_t)s0 * n_out, dl + (size_t)s0 * n_out, sn, Q, k,
+                                      td[flip].as<float>() + (size_t)g * n_out, tl[flip].as<int64_t>() + (size_t)g * n_out, nullptr));
+        }
+        dd = td[flip].as<float>(); dl = tl[flip].as<int64_t>();
+        cur_S = nxt;
+        flip ^= 1;
     }
+    MM_TRY(launch_shard_merge(st, dd, dl, cur_S, Q, k, dod, dol, doc));
     if (!out_dev) {
         MM_HIP(hipMemcpyAsync(out_dist, dod, n_out * 4, hipMemcpyDeviceToHost, st));
         MM_HIP(hipMemcpyAsync(out_labels, dol, n_out * 8, hipMemcpyDeviceToHost, st));
         if (out_count) MM_HIP(hipMemcpyAsync(out_count, doc, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
     }
-    if (!out_dev || bd.p || bl.p) MM_HIP(hipStreamSynchronize(st));
+    if (!out_dev || bd.p || bl.p || td[0].p || td[1].p) MM_HIP(hipStreamSynchronize(st));
     return MMISS_OK;
 }

@@ -45,16 +45,33 @@ class ClipShape:
 
     @classmethod
     def from_hf_config(cls, cfg) -> "ClipShape":
-        """From a transformers CLIPConfig (or its dict): the reference builds one at utils.py:41-42."""
+        """From a transformers CLIPConfig (or the dict of a checkpoint's config.json): the reference builds one at
+        utils.py:41-42. A saved config.json may omit every key whose value equals the HF default (`to_diff_dict`), so
+        missing keys fall back to CLIPVisionConfig / CLIPTextConfig's defaults (HF:configuration_clip.py:47-54,97-105,160).
+        Only `quick_gelu` towers are supported (the kernels fuse x*sigmoid(1.702x), HF:activations.py:117-123): any
+        other `hidden_act` raises instead of producing silently different embeddings."""
         d = cfg.to_dict() if hasattr(cfg, "to_dict") else dict(cfg)
-        v, t = d["vision_config"], d["text_config"]
-        return cls(v_hidden=v["hidden_size"], v_layers=v["num_hidden_layers"], v_heads=v["num_attention_heads"],
-                   v_mlp=v["intermediate_size"], v_patch=v["patch_size"], v_image=v["image_size"],
-                   t_hidden=t["hidden_size"], t_layers=t["num_hidden_layers"], t_heads=t["num_attention_heads"],
-                   t_mlp=t["intermediate_size"], t_vocab=t["vocab_size"], t_ctx=t["max_position_embeddings"],
-                   proj_dim=d.get("projection_dim", v.get("projection_dim", 512)),
-                   eos_token_id=t.get("eos_token_id", 49407) if t.get("eos_token_id") is not None else 49407,
-                   ln_eps=v.get("layer_norm_eps", 1e-5))
+        v = dict(d.get("vision_config") or d.get("vision_config_dict") or {})
+        t = dict(d.get("text_config") or d.get("text_config_dict") or {})
+        vd = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, patch_size=32,
+                  image_size=224, layer_norm_eps=1e-5, hidden_act="quick_gelu")
+        td = dict(hidden_size=512, num_hidden_layers=12, num_attention_heads=8, intermediate_size=2048, vocab_size=49408,
+                  max_position_embeddings=77, layer_norm_eps=1e-5, hidden_act="quick_gelu", eos_token_id=49407)
+        v = {**vd, **{k: x for k, x in v.items() if x is not None}}
+        t = {**td, **{k: x for k, x in t.items() if x is not None}}
+        for name, c in (("vision_config", v), ("text_config", t)):
+            if c["hidden_act"] != "quick_gelu":
+                raise ValueError(f"{name}.hidden_act = {c['hidden_act']!r}: only 'quick_gelu' towers are supported")
+        if abs(float(v["layer_norm_eps"]) - float(t["layer_norm_eps"])) > 0:
+            raise ValueError("vision and text towers with different layer_norm_eps are not supported")
+        proj = d.get("projection_dim")
+        if proj is None:
+            proj = v.get("projection_dim", t.get("projection_dim", 512))
+        return cls(v_hidden=int(v["hidden_size"]), v_layers=int(v["num_hidden_layers"]), v_heads=int(v["num_attention_heads"]),
+                   v_mlp=int(v["intermediate_size"]), v_patch=int(v["patch_size"]), v_image=int(v["image_size"]),
+                   t_hidden=int(t["hidden_size"]), t_layers=int(t["num_hidden_layers"]), t_heads=int(t["num_attention_heads"]),
+                   t_mlp=int(t["intermediate_size"]), t_vocab=int(t["vocab_size"]), t_ctx=int(t["max_position_embeddings"]),
+                   proj_dim=int(proj), eos_token_id=int(t["eos_token_id"]), ln_eps=float(v["layer_norm_eps"]))
 
     @property
     def v_tokens(self) -> int:
@@ -118,6 +135,24 @@ def random_state_dict(shape: ClipShape, seed: int = 0) -> Dict[str, np.ndarray]:
     return w
 
 
+def iter_safetensors_f32(path: str):
+    """(key, float32 C-contiguous ndarray) for every tensor of a safetensors file. Read through torch because numpy has
+    no bfloat16 (`safe_open(framework="np")` refuses bf16 checkpoints)."""
+    from safetensors import safe_open
+
+    with safe_open(path, framework="pt", device="cpu") as f:
+        for key in f.keys():
+            yield key, np.ascontiguousarray(f.get_tensor(key).float().numpy())
+
+
+def safetensors_shapes(path: str) -> Dict[str, Tuple[int, ...]]:
+    """Tensor shapes from the file header only (no tensor data is read)."""
+    from safetensors import safe_open
+
+    with safe_open(path, framework="pt", device="cpu") as f:
+        return {k: tuple(f.get_slice(k).get_shape()) for k in f.keys()}
+
+
 class ClipEncoder:
     """One encoder handle = both towers' weights in HBM + workspaces, on one GPU, one HIP stream."""
 
@@ -153,14 +188,17 @@ class ClipEncoder:
         return used, ignored
 
     def load_safetensors(self, path: str) -> Tuple[int, int]:
-        """Load a local HF-layout checkpoint (`model.safetensors`); no network access is attempted."""
-        from safetensors import safe_open
-
-        state = {}
-        with safe_open(path, framework="np") as f:
-            for k in f.keys():
-                state[k] = f.get_tensor(k).astype(np.float32)
-        return self.load_state_dict(state)
+        """Load a local HF-layout checkpoint (`model.safetensors`, f32 / f16 / bf16 tensors); no network access is
+        attempted. Tensors are widened to f32 and handed over one at a time."""
+        used = ignored = 0
+        for key, arr in iter_safetensors_f32(path):
+            u = C.c_int(0)
+            _lib.check(self._lib.mmiss_encoder_set_weight(self._h, key.encode(), arr.ctypes.data, arr.size, C.byref(u)))
+            used += u.value
+            ignored += 1 - u.value
+        _lib.check(self._lib.mmiss_encoder_finalize(self._h))
+        self._finalized = True
+        return used, ignored
 
     # ------------------------------------------------------------------ encode
     def _out(self, like, n: int):

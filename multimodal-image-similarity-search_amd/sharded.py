@@ -35,6 +35,31 @@ def merge_topk_host(dist: np.ndarray, labels: np.ndarray) -> Tuple[np.ndarray, n
     return out_l, out_d, valid.sum(axis=1).astype(np.int32)
 
 
+def exchange_topk(lab, dst, world: int, group=None, all_gather=None):
+    """X1, the ONE exchange step: every rank contributes its shard's [Q,k] (label i64, distance f32) and receives all
+    S of them -> (labels [S,Q,k] i64, distances [S,Q,k] f32). Both arrays travel in ONE all-gather of 12*Q*k bytes per
+    rank (labels then distances packed into one byte buffer): the exchange is latency-bound, so one
+    collective instead of two halves its cost. `all_gather(out, inp)` may replace torch's (bench.py's gloo rehearsal
+    stages device tensors through host memory)."""
+    import torch
+    import torch.distributed as dist
+
+    Q, k = int(lab.shape[0]), int(lab.shape[1])
+    nl, nd = Q * k * 8, Q * k * 4
+    send = torch.empty(nl + nd, dtype=torch.uint8, device=lab.device)
+    send[:nl].view(torch.int64).copy_(lab.reshape(-1))
+    send[nl:].view(torch.float32).copy_(dst.reshape(-1))
+    recv = torch.empty(world * (nl + nd), dtype=torch.uint8, device=lab.device)
+    if all_gather is not None:
+        all_gather(recv, send)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, nl + nd)
+    lab_all = recv[:, :nl].contiguous().view(torch.int64).view(world, Q, k)
+    dst_all = recv[:, nl:].contiguous().view(torch.float32).view(world, Q, k)
+    return lab_all, dst_all
+
+
 class ShardedIndex:
     """`local` is this rank's shard: any object with add(vecs, labels) / query(q, k) / count() — a FlatIndex on
     the GPU box; the CPU tests plug in an oracle-backed stand-in to exercise the collective path."""
@@ -98,15 +123,7 @@ class ShardedIndex:
         else:
             dist.broadcast(q, src=src, group=self.group)
         lab, dst, _ = self.local.query(q if dev.type == "cuda" else q.numpy(), k)
-        lab_t = torch.as_tensor(lab).to(dev)
-        dst_t = torch.as_tensor(dst).to(dev)
-        Qn = int(lab_t.shape[0])
-        lab_all = torch.empty((self.world * Qn, k), dtype=torch.int64, device=dev)     # rank-major concatenation
-        dst_all = torch.empty((self.world * Qn, k), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(lab_all, lab_t.contiguous(), group=self.group)   # X1: the one exchange step
-        dist.all_gather_into_tensor(dst_all, dst_t.contiguous(), group=self.group)
-        lab_all = lab_all.view(self.world, Qn, k)
-        dst_all = dst_all.view(self.world, Qn, k)
+        lab_all, dst_all = exchange_topk(torch.as_tensor(lab).to(dev), torch.as_tensor(dst).to(dev), self.world, self.group)
         if dev.type == "cuda":
             from .index import merge_topk
 

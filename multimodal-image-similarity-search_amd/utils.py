@@ -13,6 +13,7 @@ weights of `MMISS_CLIP_SHAPE` (vit-b-32 | longclip-l-14). With neither set load_
 """
 from __future__ import annotations
 
+import dataclasses
 import json
 import logging
 import os
@@ -22,7 +23,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from .collection import FlatCollection, PersistentClient
-from .encoder import LONGCLIP_L14, VIT_B32, ClipEncoder, ClipShape, random_state_dict
+from .encoder import LONGCLIP_L14, VIT_B32, ClipEncoder, ClipShape, random_state_dict, safetensors_shapes
 from .preprocess import ClipProcessor
 
 logger = logging.getLogger("image-match")
@@ -61,8 +62,12 @@ def load_clip_model():
         # the reference overrides the text context to MAX_TOKEN_LENGTH (utils.py:41-42); honour what the
         # checkpoint's position table actually holds
         shape = ClipShape.from_hf_config(cfg)
+        weights = os.path.join(ckpt, "model.safetensors")
+        pos = safetensors_shapes(weights).get("text_model.embeddings.position_embedding.weight")
+        if pos is not None and int(pos[0]) != shape.t_ctx:  # e.g. a LongCLIP table (248 rows) under a stock config.json (77)
+            shape = dataclasses.replace(shape, t_ctx=int(pos[0]))
         model = ClipEncoder(shape, device=_device())
-        model.load_safetensors(os.path.join(ckpt, "model.safetensors"))
+        model.load_safetensors(weights)
         processor = ClipProcessor.from_directory(ckpt, shape, max_length=min(MAX_TOKEN_LENGTH, shape.t_ctx))
     elif seed is not None:
         shape = _SHAPES[os.getenv("MMISS_CLIP_SHAPE", "vit-b-32")]
