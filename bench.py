@@ -417,6 +417,8 @@ def main():
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),
+            "exactness": dict(index.guard_stats(), note="queries served by the step's index / of them not provable from the "
+                              "first pass and widened (mmiss_index_guard_stats)"),
             "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest, "l14": l14, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
@@ -482,6 +484,7 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
             entry["other_kernels_ms"] = round(other, 4)
         res[f"Q{Q}"] = entry
     res["headline_mvec_per_s"] = res["Q1"]["mvec_per_s"]
+    res["exactness"] = idx.guard_stats()
     idx.close()
     return res
 

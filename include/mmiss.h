@@ -183,6 +183,14 @@ int mmiss_index_labels(mmiss_index* idx, int64_t* out, int64_t cap);
  */
 int mmiss_index_query(mmiss_index* idx, const float* queries, int32_t Q, int32_t k,
                       int64_t* out_labels, float* out_dist, int32_t* out_count);
+/*
+ * Exactness accounting since the index was created ("top-10 recall = 1.0" is proven per query, not assumed): the first
+ * pass ranks by approximate matrix-core scores and keeps k' > k rows; a query whose k-th exact score does not clear the
+ * best score that pass may have left out by more than the arithmetic's error bound is widened (more candidates, exact
+ * re-rank) until it does. out[0] = queries served, out[1] = queries widened, out[2] = widen rounds, out[3] = extra
+ * scan pages read. No reference analogue (chromadb's HNSW is approximate above 100 rows).
+ */
+int mmiss_index_guard_stats(mmiss_index* idx, int64_t out[4]);
 
 /* persistence of rows + labels (replaces chroma_data/, backend/app/utils.py:21,113) */
 int mmiss_index_save(mmiss_index* idx, const char* path);

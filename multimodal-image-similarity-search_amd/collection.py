@@ -16,6 +16,7 @@ handed out in insertion order; labels are the deterministic tie-break of equal d
 from __future__ import annotations
 
 import json
+import logging
 import os
 import threading
 from typing import Dict, List, Optional, Sequence
@@ -23,6 +24,9 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from .index import FlatIndex
+
+logger = logging.getLogger("image-match")
+MAX_N_RESULTS = 2040  # mmiss_index_query's per-call limit on k
 
 
 class DuplicateIDError(ValueError):
@@ -190,6 +194,9 @@ class FlatCollection:
                 if q.shape[1] != self._dim:
                     raise ValueError(f"query dimension {q.shape[1]} does not match the collection's {self._dim}")
                 k = max(1, min(int(n_results), n))  # n_results > count is not an error ("All" = 1000, main.py:757)
+                if k > MAX_N_RESULTS:  # one mmiss_index_query call ranks at most 2040 rows per query: clamp, do not fail
+                    logger.warning(f"n_results={n_results} clamped to {MAX_N_RESULTS}")
+                    k = MAX_N_RESULTS
                 labs, dist, cnt = self._index.query(q, k)
             label_to_id = dict(zip(self._labels, self._ids))
             out = {"ids": [], "distances": None, "metadatas": None, "documents": None, "embeddings": None,

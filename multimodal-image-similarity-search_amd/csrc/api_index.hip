@@ -15,6 +15,10 @@ struct mmiss_index {
     std::vector<int64_t> labels_h;
     // scratch
     DevBuf stage, qn, qs, qstage, lists_s, lists_r, lists2_s, lists2_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, gmax;
+    // exactness guard + widen pass (see "exactness contract" above mmiss_index_query)
+    DevBuf flags, nflag_d, qmap, qmap64, qs2, cand2, cur2_s, cur2_r;
+    int32_t* nflag_h = nullptr;  // pinned
+    int64_t stat_queries = 0, stat_flagged = 0, stat_rounds = 0, stat_pages = 0;
     hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
 };
 
@@ -164,9 +168,14 @@ extern "C" int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device
         delete ix;
         MM_FAIL(MMISS_ERR_HIP, "hipStreamCreate failed");
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&ix->nflag_h), 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(ix->own_stream);
+        delete ix;
+        MM_FAIL(MMISS_ERR_HIP, "hipHostMalloc failed");
+    }
     if (capacity_hint > 0) {
         int rc = index_reserve(ix, capacity_hint, ix->own_stream);
-        if (rc != MMISS_OK) { (void)hipStreamDestroy(ix->own_stream); delete ix; return rc; }
+        if (rc != MMISS_OK) { (void)hipStreamDestroy(ix->own_stream); (void)hipHostFree(ix->nflag_h); delete ix; return rc; }
     }
     *out = ix;
     return MMISS_OK;
@@ -177,6 +186,7 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
+    if (ix->nflag_h) (void)hipHostFree(ix->nflag_h);
     delete ix;
     return MMISS_OK;
 }
@@ -363,6 +373,129 @@ extern "C" int mmiss_index_labels(mmiss_index* ix, int64_t* out, int64_t cap) {
     return MMISS_OK;
 }
 
+// ================================================================================================ exactness contract
+// Stage 1 orders rows by APPROXIMATE scores (matrix cores, f32 accumulation, f16 query operand for f16 rows) and keeps
+// k' > k of them; stage 2 re-scores the survivors canonically (fp64, fixed order) and sorts. That is exact by construction
+// only if no row left out by stage 1 can belong to the true top-k, so stage 2 PROVES it per query:
+//   every left-out row r has approx(r) <= tau (tau = the k'-th approximate score / group maximum, the paging cursor),
+//   |approx(r) - canonical(r)| <= eps for every row (bound below), so canonical(r) <= tau + eps;
+//   if the k-th canonical score c_k of the candidates satisfies c_k - tau > eps, nothing left out reaches c_k.
+// A query that fails the test is WIDENED: it is re-run through the paging scan (rows strictly after the cursor, 32 per
+// page), rounds of geometrically more pages, each round re-ranking {best rows so far} + {new pages}, until the test
+// passes or the cursor runs off the index. Exact for any data (near-duplicates, thousands of ties); on random data the
+// test fails for about one query in 10^4 (k = 10: the gap between the 10th and the 16th best score vs eps ~ 6e-4).
+namespace {
+
+double guard_eps(const mmiss_index* ix) {
+    // f32 accumulation of D exact products in hardware order: <= 4 D 2^-24 sum|q_d c_d| (factor 4: margin for the MFMA's
+    // internal alignment/truncation) <= 4 D 2^-24 |q||c|.  f16 rows: the scan's query operand is f16(qn), |f16(x) - x| <=
+    // 2^-11 |x| (+ 2^-25 in the subnormal range), so the operand rounding moves a score by <= 2^-11 |q||c| + D 2^-25.
+    // |q||c| <= (1 + 2^-10)^2; the float rounding of the canonical distance (<= 2) is 2^-23 at most.
+    const double D = ix->dim;
+    double e = 4.0 * D * ldexp(1.0, -24);
+    if (ix->dtype == MMISS_F16) e += ldexp(1.0, -11) + D * ldexp(1.0, -25);
+    return e * 1.003 + ldexp(1.0, -21);
+}
+
+int launch_rerank(mmiss_index* ix, hipStream_t st, const RerankArgs& r, int blocks) {
+    int npow = 1;
+    while (npow < r.ncand) npow <<= 1;
+    const int lds = npow * 8 + 16;
+    MM_PROF("rerank", st, 2.0 * blocks * r.ncand * r.D, (double)blocks * r.ncand * r.D * ix->elt);
+    const int threads = r.ncand >= 16 ? 1024 : 256;  // one wave per candidate row: more waves hide the gather latency
+    if (ix->dtype == MMISS_F16)
+        hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(blocks), dim3(threads), lds, st, r);
+    else
+        hipLaunchKernelGGL(rerank_kernel<float>, dim3(blocks), dim3(threads), lds, st, r);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+// number of flagged queries of the rerank just launched (host value; synchronises the stream)
+int read_nflag(mmiss_index* ix, hipStream_t st, int* n) {
+    MM_HIP(hipMemcpyAsync(ix->nflag_h, ix->nflag_d.p, 4, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    *n = *ix->nflag_h;
+    return MMISS_OK;
+}
+
+// the widen pass for the queries listed in `which` (original indices); results overwrite their rows of d_lab / d_dist / d_cnt
+int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& which, int k, int64_t* d_lab, float* d_dist,
+                  int32_t* d_cnt) {
+    const int Qf = (int)which.size(), D = ix->dim, KP = 32, CAPF = 4096;
+    const int64_t N = ix->count;
+    const int kk = (int)std::min<int64_t>(k, N);
+    const int kkpad = (int)round_up(std::max(kk, 1), KP);
+    const int Qfp = (int)round_up(Qf, 64);
+    std::vector<int64_t> map64(which.begin(), which.end());
+    MM_TRY(ix->qmap.ensure((size_t)Qf * 4));
+    MM_TRY(ix->qmap64.ensure((size_t)Qf * 8));
+    MM_TRY(ix->qs2.ensure((size_t)Qfp * D * ix->elt));
+    MM_TRY(ix->cand2.ensure((size_t)Qf * CAPF * 4));
+    MM_TRY(ix->cur2_s.ensure((size_t)Qf * 4));
+    MM_TRY(ix->cur2_r.ensure((size_t)Qf * 4));
+    std::vector<float> inf((size_t)Qf, INFINITY);
+    std::vector<int32_t> neg((size_t)Qf, -1);
+    MM_HIP(hipMemcpyAsync(ix->qmap.p, which.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
+    MM_HIP(hipMemcpyAsync(ix->qmap64.p, map64.data(), (size_t)Qf * 8, hipMemcpyHostToDevice, st));
+    MM_HIP(hipMemcpyAsync(ix->cur2_s.p, inf.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
+    MM_HIP(hipMemcpyAsync(ix->cur2_r.p, neg.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
+    MM_HIP(hipMemsetAsync(ix->qs2.p, 0, (size_t)Qfp * D * ix->elt, st));
+    MM_HIP(hipMemsetAsync(ix->cand2.p, 0xff, (size_t)Qf * CAPF * 4, st));  // all -1
+    {
+        const int grid = (int)std::min<int64_t>(4096, ((int64_t)Qf * D + 255) / 256);
+        if (ix->dtype == MMISS_F16)
+            hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->qs.as<_Float16>(),
+                               ix->qmap64.as<int64_t>(), ix->qs2.as<_Float16>(), (int64_t)Qf, D);
+        else
+            hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, st, ix->qs.as<float>(),
+                               ix->qmap64.as<int64_t>(), ix->qs2.as<float>(), (int64_t)Qf, D);
+        MM_HIP(hipGetLastError());
+    }
+    MM_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
+    const ScanPlan p = plan_scan(D, ix->elt, Qf, KP, N);
+    MM_TRY(ix->lists_s.ensure((size_t)p.slabs * Qf * KP * 4));
+    MM_TRY(ix->lists_r.ensure((size_t)p.slabs * Qf * KP * 4));
+    const int pmax = (CAPF - kkpad) / KP;
+    int pages = kkpad / KP + 1;  // first round: room for k results and one page of slack
+    for (int round = 0;; ++round) {
+        if (pages > pmax) pages = pmax;
+        for (int page = 0; page < pages; ++page) {
+            ScanArgs a{};
+            a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = ix->qs2.p; a.Q = Qf;
+            a.cur_s = ix->cur2_s.as<float>(); a.cur_r = ix->cur2_r.as<int32_t>();
+            a.kp = KP; a.tiles_per_block = p.tiles_per_block;
+            a.out_s = ix->lists_s.as<float>(); a.out_r = ix->lists_r.as<int32_t>();
+            MM_TRY(launch_scan(ix, st, a, p));
+            MergeArgs m{};
+            m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
+            m.L = p.slabs; m.Q = Qf; m.kp = KP;
+            m.cand = ix->cand2.as<int32_t>(); m.cand_stride = CAPF; m.page_off = kkpad + page * KP;
+            m.cur_s = ix->cur2_s.as<float>(); m.cur_r = ix->cur2_r.as<int32_t>();
+            MM_TRY(launch_merge(ix, st, m));
+        }
+        ix->stat_pages += pages;
+        MM_HIP(hipMemsetAsync(ix->nflag_d.p, 0, 4, st));
+        RerankArgs r{};
+        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand2.as<int32_t>();
+        r.cand_stride = CAPF; r.ncand = kkpad + pages * KP; r.group_mode = 0; r.nrows = N;
+        r.labels = ix->labels_d.as<int64_t>(); r.k = k;
+        r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
+        r.qmap = ix->qmap.as<int32_t>(); r.out_rows = ix->cand2.as<int32_t>();
+        r.tau = ix->cur2_s.as<float>(); r.eps = guard_eps(ix);
+        r.flags = ix->flags.as<int32_t>(); r.nflag = ix->nflag_d.as<int32_t>();
+        MM_TRY(launch_rerank(ix, st, r, Qf));
+        int left = 0;
+        MM_TRY(read_nflag(ix, st, &left));
+        ix->stat_rounds += 1;
+        if (left == 0) return MMISS_OK;
+        if (round >= 48) MM_FAIL(MMISS_ERR_STATE, "mmiss_index_query: widen pass did not converge (%d queries left)", left);
+        pages *= 2;
+    }
+}
+
+}  // namespace
+
 // ================================================================================================ query
 extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t Q, int32_t k, int64_t* out_labels,
                                  float* out_dist, int32_t* out_count) {
@@ -425,6 +558,16 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     // batched path: f16 rows, more than one MFMA tile of queries, single page
     const bool dense = (N > 0) && ix->dtype == MMISS_F16 && Q > 16 && pages == 1;
     MM_TRY(ix->cand.ensure((size_t)Q * ncand * 4));
+    // (score, row) of the last candidate stage 1 kept per query, -inf when it kept every row: the paging cursor, and the
+    // guard's bound on what was left out
+    MM_TRY(ix->cur_s.ensure((size_t)Q * 4));
+    MM_TRY(ix->cur_r.ensure((size_t)Q * 4));
+    const bool guard = N > 0 && mmiss_option("exact_guard", 1) != 0;
+    if (guard) {
+        MM_TRY(ix->flags.ensure((size_t)Q * 4));
+        MM_TRY(ix->nflag_d.ensure(64));
+        MM_HIP(hipMemsetAsync(ix->nflag_d.p, 0, 4, st));
+    }
     if (N == 0) {
         MM_HIP(hipMemsetAsync(ix->cand.p, 0xff, (size_t)Q * ncand * 4, st));  // all -1
     } else if (dense) {
@@ -470,6 +613,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
         m.L = splits; m.Q = Q; m.kp = kp;
         m.cand = ix->cand.as<int32_t>(); m.cand_stride = ncand; m.page_off = 0;
+        m.cur_s = ix->cur_s.as<float>(); m.cur_r = ix->cur_r.as<int32_t>();  // k'-th group maximum
         MM_TRY(launch_merge(ix, st, m));
     } else {
         const ScanPlan p = plan_scan(D, ix->elt, Q, kp, N);
@@ -477,8 +621,6 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         MM_TRY(ix->lists_r.ensure((size_t)p.slabs * Q * kp * 4));
         const bool paging = pages > 1;
         if (paging) {
-            MM_TRY(ix->cur_s.ensure((size_t)Q * 4));
-            MM_TRY(ix->cur_r.ensure((size_t)Q * 4));
             std::vector<float> inf((size_t)Q, INFINITY);
             std::vector<int32_t> neg((size_t)Q, -1);
             MM_HIP(hipMemcpyAsync(ix->cur_s.p, inf.data(), (size_t)Q * 4, hipMemcpyHostToDevice, st));
@@ -497,8 +639,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
             m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
             m.L = p.slabs; m.Q = Q; m.kp = kp;
             m.cand = ix->cand.as<int32_t>(); m.cand_stride = ncand; m.page_off = page * kp;
-            m.cur_s = paging ? ix->cur_s.as<float>() : nullptr;
-            m.cur_r = paging ? ix->cur_r.as<int32_t>() : nullptr;
+            m.cur_s = ix->cur_s.as<float>(); m.cur_r = ix->cur_r.as<int32_t>();  // the scan reads them only when paging
             MM_TRY(launch_merge(ix, st, m));
         }
     }
@@ -508,16 +649,26 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         r.cand_stride = ncand; r.ncand = dense ? ncand * 16 : ncand; r.group_mode = dense ? 1 : 0; r.nrows = N;
         r.labels = ix->labels_d.as<int64_t>(); r.k = k;
         r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
-        int npow = 1;
-        while (npow < r.ncand) npow <<= 1;
-        const int lds = npow * 12 + 16;
-        MM_PROF("rerank", st, 2.0 * Q * r.ncand * D, (double)Q * r.ncand * D * ix->elt);
-        const int threads = r.ncand >= 16 ? 1024 : 256;  // one wave per candidate row: more waves hide the gather latency
-        if (ix->dtype == MMISS_F16)
-            hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(Q), dim3(threads), lds, st, r);
-        else
-            hipLaunchKernelGGL(rerank_kernel<float>, dim3(Q), dim3(threads), lds, st, r);
-        MM_HIP(hipGetLastError());
+        if (guard) {
+            r.tau = ix->cur_s.as<float>(); r.eps = guard_eps(ix);
+            r.flags = ix->flags.as<int32_t>(); r.nflag = ix->nflag_d.as<int32_t>();
+            r.force_flag = mmiss_option("guard_force", 0);
+        }
+        MM_TRY(launch_rerank(ix, st, r, Q));
+    }
+    ix->stat_queries += Q;
+    if (guard) {
+        // one 4-byte read-back per call: how many queries could not be proven exact (almost always 0)
+        int nflag = 0;
+        MM_TRY(read_nflag(ix, st, &nflag));
+        if (nflag > 0) {
+            std::vector<int32_t> fl((size_t)Q), which;
+            MM_HIP(hipMemcpy(fl.data(), ix->flags.p, (size_t)Q * 4, hipMemcpyDeviceToHost));
+            for (int q = 0; q < Q; ++q)
+                if (fl[q]) which.push_back(q);
+            ix->stat_flagged += (int64_t)which.size();
+            MM_TRY(widen_queries(ix, st, which, k, d_lab, d_dist, d_cnt));
+        }
     }
     if (!out_dev) {
         MM_HIP(hipMemcpyAsync(out_labels, d_lab, (size_t)Q * k * 8, hipMemcpyDeviceToHost, st));
@@ -527,6 +678,13 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     } else if (!ix->has_user_stream) {
         MM_HIP(hipStreamSynchronize(st));
     }
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_guard_stats(mmiss_index* ix, int64_t out[4]) {
+    if (!ix || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_guard_stats: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    out[0] = ix->stat_queries; out[1] = ix->stat_flagged; out[2] = ix->stat_rounds; out[3] = ix->stat_pages;
     return MMISS_OK;
 }
 

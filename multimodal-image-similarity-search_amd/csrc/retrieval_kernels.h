@@ -540,40 +540,52 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
 struct RerankArgs {
     const void* rows; int D;
     const float* qn;        // [Q, D] canonical-normalised queries
-    const int32_t* cand;    // [Q][cand_stride]
+    const int32_t* cand;    // [blocks][cand_stride]
     int cand_stride, ncand;
     int group_mode;         // 1: cand holds GROUPMAX group ids, candidate c -> member c & 15 of group cand[c >> 4]
     int64_t nrows;          // rows in the index (group members beyond it are skipped)
-    const int64_t* labels;  // [N] row -> label
+    const int64_t* labels;  // [N] row -> label (strictly increasing with the row: (dist, row) order == (dist, label) order)
     int k;
     int64_t* out_labels;    // [Q, k]
     float* out_dist;        // [Q, k]
     int32_t* out_count;     // [Q]
+    // widen pass: block b serves query qmap[b] (null: b) and also returns its k best ROWS (they seed the next round)
+    const int32_t* qmap;
+    int32_t* out_rows;      // [blocks][cand_stride], first k_eff entries written, or null
+    // exactness guard (see api_index.hip "exactness contract"): tau[b] = stage 1's bound on the approximate score of every
+    // row that is NOT among the candidates (-inf: every row is a candidate). The result is proven exact when the k-th
+    // canonical score clears tau by more than eps; otherwise flags[b] = 1 and *nflag counts it.
+    const float* tau;
+    double eps;
+    int32_t* flags;
+    int32_t* nflag;
+    int force_flag;         // tests: flag every query whose candidate list was full
 };
 
 template <typename T>
 __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // sort buffer: npow2 entries of (dist f32, label i64)
+    // sort buffer: npow2 entries of (dist f32, row i32)
     int npow = 1;
     while (npow < a.ncand) npow <<= 1;
     float* sd = reinterpret_cast<float*>(smem);
-    int64_t* sl = reinterpret_cast<int64_t*>(smem + (size_t)npow * 4 + ((npow & 1) ? 4 : 0));
+    int32_t* sr = reinterpret_cast<int32_t*>(smem + (size_t)npow * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = blockIdx.x;
+    const int b = blockIdx.x;
+    const int q = a.qmap ? a.qmap[b] : b;
     const float* qv = a.qn + (size_t)q * a.D;
     const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
-    for (int i = tid; i < npow; i += nthreads) { sd[i] = INFINITY; sl[i] = INT64_MAX; }
+    for (int i = tid; i < npow; i += nthreads) { sd[i] = INFINITY; sr[i] = INT32_MAX; }
     __syncthreads();
     for (int c = wave; c < a.ncand; c += nwaves) {
         int64_t row;
         if (a.group_mode) {
-            const int g = a.cand[(size_t)q * a.cand_stride + (c >> 4)];
+            const int g = a.cand[(size_t)b * a.cand_stride + (c >> 4)];
             if (g < 0) continue;  // wave-uniform
             row = groupmax_row(g, c & 15);
             if (row >= a.nrows) continue;
         } else {
-            row = a.cand[(size_t)q * a.cand_stride + c];
+            row = a.cand[(size_t)b * a.cand_stride + c];
             if (row < 0) continue;  // wave-uniform
         }
         const T* rv = reinterpret_cast<const T*>(a.rows) + (size_t)row * a.D;
@@ -582,39 +594,57 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
         const double dot = wave_butterfly_sum(acc);
         if (lane == 0) {
             sd[c] = (float)(1.0 - dot);
-            sl[c] = a.labels[row];
+            sr[c] = (int32_t)row;
         }
     }
     __syncthreads();
-    // block bitonic sort ascending by (dist, label); NaN distances sort last
+    // block bitonic sort ascending by (dist, row); NaN distances sort last
     for (int k = 2; k <= npow; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < npow; i += nthreads) {
                 const int p = i ^ j;
                 if (p > i) {
                     const float di = sd[i], dp = sd[p];
-                    const int64_t li = sl[i], lp = sl[p];
+                    const int32_t li = sr[i], lp = sr[p];
                     const bool up = (i & k) == 0;
                     // "i before p" in the final order?
                     const bool i_first = (di < dp) || (di == dp && li < lp) || (dp != dp && di == di);
                     const bool p_first = (dp < di) || (dp == di && lp < li) || (di != di && dp == dp);
                     const bool swap = up ? p_first : i_first;
-                    if (swap) { sd[i] = dp; sd[p] = di; sl[i] = lp; sl[p] = li; }
+                    if (swap) { sd[i] = dp; sd[p] = di; sr[i] = lp; sr[p] = li; }
                 }
             }
             __syncthreads();
         }
     }
-    int nvalid = 0;
     for (int i = tid; i < a.k; i += nthreads) {
-        const bool ok = i < npow && sl[i] != INT64_MAX;
-        a.out_labels[(size_t)q * a.k + i] = ok ? sl[i] : -1;
+        const bool ok = i < npow && sr[i] != INT32_MAX;
+        a.out_labels[(size_t)q * a.k + i] = ok ? a.labels[sr[i]] : -1;
         a.out_dist[(size_t)q * a.k + i] = ok ? sd[i] : INFINITY;
     }
+    const int64_t k_eff = (int64_t)a.k < a.nrows ? (int64_t)a.k : a.nrows;  // results that exist
+    if (a.out_rows) {
+        for (int i = tid; i < a.cand_stride && i < (int)((k_eff + 31) & ~31LL); i += nthreads)
+            a.out_rows[(size_t)b * a.cand_stride + i] = (i < k_eff && i < npow && sr[i] != INT32_MAX) ? sr[i] : -1;
+    }
     if (tid == 0) {
+        int nvalid = 0;
         const int lim = a.k < npow ? a.k : npow;
-        for (int i = 0; i < lim; ++i) nvalid += (sl[i] != INT64_MAX);
+        for (int i = 0; i < lim; ++i) nvalid += (sr[i] != INT32_MAX);
         a.out_count[q] = nvalid;
+        if (a.flags) {
+            int flag = 0;
+            const float t = a.tau ? a.tau[b] : SCAN_NEG_INF;
+            if (t > SCAN_NEG_INF) {  // stage 1 left rows out: every one of them has an approximate score <= t
+                if (nvalid < k_eff || a.force_flag) flag = 1;
+                else {
+                    const double ck = 1.0 - (double)sd[k_eff - 1];  // k-th canonical score (its float rounding is inside eps)
+                    if (!(ck - (double)t > a.eps)) flag = 1;
+                }
+            }
+            a.flags[b] = flag;
+            if (flag) atomicAdd(a.nflag, 1);
+        }
     }
 }
 

@@ -118,6 +118,13 @@ class FlatIndex:
         _lib.check(self._lib.mmiss_index_query(self._h, _lib.ptr(q), Q, int(k), _lib.ptr(lab), _lib.ptr(dist), _lib.ptr(cnt)))
         return lab, dist, cnt
 
+    def guard_stats(self) -> dict:
+        """Exactness accounting (mmiss_index_guard_stats): queries served, queries whose first pass could not be proven
+        exact and were widened, widen rounds, extra scan pages."""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.mmiss_index_guard_stats(self._h, out))
+        return {"queries": out[0], "widened": out[1], "rounds": out[2], "pages": out[3]}
+
     # ------------------------------------------------------------------ persistence
     def save(self, path: str) -> None:
         _lib.check(self._lib.mmiss_index_save(self._h, str(path).encode()))
