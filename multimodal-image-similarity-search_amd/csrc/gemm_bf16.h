@@ -174,6 +174,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+    // BIAS_RESID_F32: the residual rows this wave will add to, ALL fetched now (JT x 4 16-byte loads per lane in flight
+    // while the first accumulator rows go through the transpose). Loaded where they are used they were JT x 4 dependent
+    // round trips per wave — load, s_waitcnt vmcnt(0) (which also waits for the previous store), add, store — and that
+    // chain, not bandwidth, was the 15-25 us "fixed cost" of the out-proj / FC2 launches. Rows up to the padded M exist
+    // (the caller pads the residual stream), so only the stores are masked by m_valid.
+    f32x4 resid[EPI == MMISS_EPI_BIAS_RESID_F32 ? JT : 1][2][2];
+    if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    resid[j][rh][ch] = *reinterpret_cast<const f32x4*>(
+                        reinterpret_cast<const float*>(ep.out) + (size_t)(m_wave + j * 16 + rh * 8 + rrow) * ep.ldo + n_wave +
+                        ch * 32 + rchunk * 4);
+    }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         // ---- transpose-in: lane (fr = row, fg) owns columns i*16 + 4*fg .. +3
@@ -228,7 +245,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
                             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n) = v;
                         } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
                             float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
-                            v = *reinterpret_cast<const f32x4*>(p) + v;
+                            v = resid[j][rh][ch] + v;
                             // folded-LayerNorm mode: the next kernel reads the bf16 copy, not the f32 stream, so the f32 rows
                             // are stored non-temporally and leave the L2 to the bf16 rows
                             if (ep.xb_out || (ep.nt_out & 1)) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
