@@ -55,6 +55,19 @@ int mmiss_dbg_encoder_set_fuse_ln(struct mmiss_encoder* enc, int on);
 int mmiss_dbg_gemm_split_time(int device, int epi, int bm, const void* A, const void* W, void* out, const float* bias,
                               int32_t M, int32_t N, int32_t K, int32_t iters, float* ms);
 
+/* fp8 path in isolation (gemm_fp8.h). Scale arrays use the permuted E8M0 layout: 16 * ceil(K / 512) bytes per row, the
+ * scale of k-block b = k / 32 at byte (b / 16) * 16 + (b % 4) * 4 + (b / 4) % 4. */
+int mmiss_dbg_quantize_weights_fp8(int device, void* hip_stream, const void* w_bf16, void* w8, float* scale, int32_t N,
+                                   int32_t K);
+int mmiss_dbg_layernorm_mxfp8(int device, void* hip_stream, const float* x, const float* gamma, const float* beta,
+                              void* out8, void* out_scale, int32_t M, int32_t d, float eps);
+/* epi: 0 out bf16 = acc * wscale[n] + bias[n]; 1 out e4m3 + out_scale = mx(quick_gelu(.)); 2 out f32 += . ; bm = 128 | 160 | 192 */
+int mmiss_dbg_gemm8(int device, void* hip_stream, int epi, int bm, const void* A8, const void* As, const void* W8,
+                    const float* wscale, const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K);
+int mmiss_dbg_gemm8_time(int device, int epi, int bm, const void* A8, const void* As, const void* W8, const float* wscale,
+                         const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K, int32_t iters,
+                         float* ms_per_launch);
+
 /* process-wide integer tuning knob (A/B experiments from tools/): e.g. "scan_group" = 8 | 16 */
 int mmiss_dbg_set_option(const char* key, int value);
 

@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libmmiss.so")
 MMISS_OK = 0
 MMISS_F32 = 0
 MMISS_F16 = 1
+MMISS_PREC_BF16 = 0
+MMISS_PREC_FP8 = 1
 
 EPI_F32, EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_PATCH_F32 = range(5)
 
@@ -56,6 +58,7 @@ SIGNATURES = {
     "mmiss_encoder_destroy": (_I, [_P]),
     "mmiss_encoder_set_weight": (_I, [_P, C.c_char_p, _P, _I64, C.POINTER(_I)]),
     "mmiss_encoder_finalize": (_I, [_P]),
+    "mmiss_encoder_set_precision": (_I, [_P, _I32]),
     "mmiss_encoder_set_stream": (_I, [_P, _P, _I32]),
     "mmiss_encode_image": (_I, [_P, _P, _I32, _P]),
     "mmiss_encode_image_u8": (_I, [_P, _P, _I32, _P]),
@@ -93,6 +96,10 @@ SIGNATURES = {
     "mmiss_dbg_encoder_record_taps": (_I, [_P, _I]),
     "mmiss_dbg_encoder_set_fuse_ln": (_I, [_P, _I]),
     "mmiss_dbg_set_option": (_I, [C.c_char_p, _I]),
+    "mmiss_dbg_quantize_weights_fp8": (_I, [_I, _P, _P, _P, _P, _I32, _I32]),
+    "mmiss_dbg_layernorm_mxfp8": (_I, [_I, _P, _P, _P, _P, _P, _P, _I32, _I32, C.c_float]),
+    "mmiss_dbg_gemm8": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32]),
+    "mmiss_dbg_gemm8_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.POINTER(C.c_float)]),
     "mmiss_dbg_gemm_split_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.POINTER(C.c_float)]),
 }
 

@@ -4,6 +4,7 @@
 #include "gemm_bf16.h"
 #include "gemm_bf16_256.h"
 #include "gemm_bf16_ring.h"
+#include "gemm_fp8.h"
 #include "encoder_kernels.h"
 #include "preprocess_kernels.h"
 #include <map>
@@ -38,6 +39,7 @@ __global__ void gather_rows16_kernel(const char* __restrict__ src, const int32_t
 struct LayerW {
     DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, ln2g, ln2b, w1, b1, w2, b2;
     DevBuf wqkv_f, cqkv, bqkv_f, w1_f, c1, b1_f;  // LayerNorm folded into the QKV / FC1 weights (finalize)
+    DevBuf wqkv8, sqkv, w1_8, s1, w2_8, s2;       // fp8 path: e4m3 weights + per-output-channel f32 scales
 };
 
 struct Tower {
@@ -53,6 +55,8 @@ struct Tower {
     DevBuf stats;             // [Mp][hidden/64][2] partial row (sum, sumsq) for the LayerNorm-fused GEMMs
     DevBuf xb;                // bf16 copy of the residual stream (A operand of the LayerNorm-folded GEMMs)
     DevBuf splitk;            // f32 partial products of the split-K GEMMs (middle batch sizes), allocated on demand
+    DevBuf h8, hs, u8, us;    // fp8 path: MXFP8 LayerNorm output / FC1 output (e4m3 bytes + permuted E8M0 block scales)
+    bool fp8_ready = false;   // fp8 weights built for this tower
     bool pooled_compact = false;
     int last_B = 0, last_T = 0;
     int64_t tap_stride = 0;  // floats per recorded tap
@@ -92,6 +96,9 @@ struct mmiss_encoder {
     //     its 256 x 256 tile): 4.54 vs 4.74 k images/s.
     // -1 (default) = automatic: 2 from `ln_fold_min_rows` (6000) rows per call when hidden <= 768, else 0.
     int ln_mode = -1;
+    // MMISS_PREC_FP8: the QKV / FC1 / FC2 GEMMs of calls with at least `fp8_min_rows` rows run on the block-scaled fp8
+    // MFMA (gemm_fp8.h); out-proj, the pruned last layer, the embeddings and the head stay bf16
+    int precision = MMISS_PREC_BF16;
 
     Tower vis, txt;
     // vision-only
@@ -199,6 +206,12 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     MM_TRY(alloc_zero(tw.uc, (size_t)Bp * tw.mlp * 2));
     MM_TRY(alloc_zero(tw.stats, (size_t)Mp * (d / 64) * 2 * 4));
     MM_TRY(alloc_zero(tw.xb, (size_t)Mp * d * 2));
+    if (e->precision == MMISS_PREC_FP8) {
+        MM_TRY(alloc_zero(tw.h8, (size_t)Mp * d));
+        MM_TRY(alloc_zero(tw.hs, (size_t)Mp * mx_scale_row_bytes(d)));
+        MM_TRY(alloc_zero(tw.u8, (size_t)Mp * tw.mlp));
+        MM_TRY(alloc_zero(tw.us, (size_t)Mp * mx_scale_row_bytes(tw.mlp)));
+    }
     if (e->record_taps) {
         tw.tap_stride = Mp * d;
         MM_TRY(alloc_zero(tw.taps, (size_t)(tw.layers + 1) * tw.tap_stride * 4));
@@ -218,6 +231,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         const int forced = mmiss_option("ln_mode", -1);
         mode = forced >= 0 ? forced : ((M >= mmiss_option("ln_fold_min_rows", 6000) && d <= 768) ? 2 : 0);
     }
+    const bool fp8 = e->precision == MMISS_PREC_FP8 && tw.fp8_ready && tw.h8.p && M >= mmiss_option("fp8_min_rows", 1024);
+    if (fp8) mode = 0;  // the fp8 GEMMs take their A operand from the MXFP8 LayerNorm kernel
     const bool plain = mode == 0;
     int bm_qkv = plain ? gemm_pick_variant(M, 3 * d) : gemm_pick_bm(M, 3 * d);
     int bm_d = plain ? gemm_pick_variant(M, d) : gemm_pick_bm(M, d);
@@ -227,6 +242,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     if (const int f = mmiss_option("gemm_bm_d", 0)) bm_d = f;
     if (const int f = mmiss_option("gemm_bm_mlp", 0)) bm_mlp = f;
     auto padded = [&](int bm) { return (int)round_up(M, bm % 1000); };
+    const int bm8_qkv = gemm_pick_bm(M, 3 * d), bm8_d = gemm_pick_bm(M, d), bm8_mlp = gemm_pick_bm(M, tw.mlp);
     // 256 x 256 phase-pipelined tile for the widest GEMMs: from N = 4096 (the ViT-L/14 FC1: 336 -> 320 us inside the bs-128
     // encode, +2 % images/s; the L/14 QKV at N = 3072 and the B/32 GEMMs do not gain). Option gemm_256 = minimum N, 0 = never.
     const int min_n256 = mmiss_option("gemm_256", 4096);
@@ -266,6 +282,14 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln1g.as<float>(); ep.ln_b = L.ln1b.as<float>();
             ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.x.as<float>(), L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
+        } else if (fp8) {
+            MM_TRY(launch_layernorm_mxfp8(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h8.as<uint8_t>(),
+                                          tw.hs.as<uint8_t>(), M, d, eps));
+            Gemm8Args g{};
+            g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
+            g.W = L.wqkv8.as<uint8_t>(); g.wscale = L.sqkv.as<float>(); g.bias = L.bqkv.as<float>();
+            g.out = tw.qkv.p; g.ldo = 3 * d; g.M = padded(bm8_qkv); g.N = 3 * d; g.K = d; g.m_valid = M;
+            MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_BF16, bm8_qkv, g));
         } else {
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
@@ -310,6 +334,23 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln2g.as<float>(); ep.ln_b = L.ln2b.as<float>();
             ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.x.as<float>(), L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
+        } else if (fp8) {
+            // LN2 -> MXFP8, FC1 + QuickGELU -> MXFP8 (per row and 64 columns), FC2 + residual: `u` crosses HBM as 1 byte
+            MM_TRY(launch_layernorm_mxfp8(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h8.as<uint8_t>(),
+                                          tw.hs.as<uint8_t>(), M, d, eps));
+            Gemm8Args g{};
+            g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
+            g.W = L.w1_8.as<uint8_t>(); g.wscale = L.s1.as<float>(); g.bias = L.b1.as<float>();
+            g.out = tw.u8.p; g.out_scale = tw.us.as<uint8_t>(); g.ld_os = mx_scale_row_bytes(tw.mlp);
+            g.ldo = tw.mlp; g.M = padded(bm8_mlp); g.N = tw.mlp; g.K = d; g.m_valid = M;
+            MM_TRY(launch_gemm8(st, MMISS_EPI8_QGELU_MXFP8, bm8_mlp, g));
+            g = Gemm8Args{};
+            g.A = tw.u8.as<uint8_t>(); g.As = tw.us.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(tw.mlp);
+            g.W = L.w2_8.as<uint8_t>(); g.wscale = L.s2.as<float>(); g.bias = L.b2.as<float>();
+            g.out = tw.x.p; g.ldo = d; g.M = padded(bm8_d); g.N = d; g.K = tw.mlp; g.m_valid = M;
+            MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_RESID_F32, bm8_d, g));
+            MM_TRY(tap(l + 1));
+            continue;
         } else {
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
@@ -608,6 +649,8 @@ extern "C" int mmiss_encoder_set_weight(mmiss_encoder* enc, const char* hf_key, 
     return MMISS_OK;
 }
 
+static int build_fp8_weights(mmiss_encoder* enc);
+
 extern "C" int mmiss_encoder_finalize(mmiss_encoder* enc) {
     if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
     std::lock_guard<std::mutex> lk(enc->mu);
@@ -638,7 +681,45 @@ extern "C" int mmiss_encoder_finalize(mmiss_encoder* enc) {
     }
     MM_HIP(hipGetLastError());
     MM_HIP(hipStreamSynchronize(enc->own_stream));
+    if (enc->precision == MMISS_PREC_FP8) MM_TRY(build_fp8_weights(enc));
     enc->finalized = true;
+    return MMISS_OK;
+}
+
+// e4m3 copies of the QKV / FC1 / FC2 weights with per-output-channel scales (from the bf16 weights: 8 -> 3 mantissa bits)
+static int build_fp8_weights(mmiss_encoder* enc) {
+    hipStream_t st = enc->own_stream;
+    for (Tower* tw : {&enc->vis, &enc->txt}) {
+        if (tw->fp8_ready) continue;
+        const int d = tw->hidden, mlp = tw->mlp;
+        auto quant = [&](DevBuf& wb, DevBuf& w8, DevBuf& sc, int N, int K) -> int {
+            MM_TRY(w8.alloc((size_t)N * K));
+            MM_TRY(sc.alloc((size_t)N * 4));
+            hipLaunchKernelGGL(quantize_weights_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, st, wb.as<uint16_t>(),
+                               w8.as<uint8_t>(), sc.as<float>(), N, K);
+            MM_HIP(hipGetLastError());
+            return MMISS_OK;
+        };
+        for (LayerW& L : tw->L) {
+            MM_TRY(quant(L.wqkv, L.wqkv8, L.sqkv, 3 * d, d));
+            MM_TRY(quant(L.w1, L.w1_8, L.s1, mlp, d));
+            MM_TRY(quant(L.w2, L.w2_8, L.s2, d, mlp));
+        }
+        tw->fp8_ready = true;
+    }
+    MM_HIP(hipStreamSynchronize(st));
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_encoder_set_precision(mmiss_encoder* enc, int32_t precision) {
+    if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
+    if (precision != MMISS_PREC_BF16 && precision != MMISS_PREC_FP8) MM_FAIL(MMISS_ERR_ARG, "unknown precision %d", precision);
+    std::lock_guard<std::mutex> lk(enc->mu);
+    MM_TRY(mmiss_use_device(enc->device));
+    MM_HIP(hipStreamSynchronize(enc->stream()));
+    if (precision == MMISS_PREC_FP8 && enc->finalized) MM_TRY(build_fp8_weights(enc));
+    if (precision != enc->precision) { enc->vis.ws_batch = 0; enc->txt.ws_batch = 0; }  // (re)allocate workspaces with the fp8 buffers
+    enc->precision = precision;
     return MMISS_OK;
 }
 
@@ -1020,5 +1101,57 @@ extern "C" int mmiss_dbg_gemm_split_time(int device, int epi, int bm, const void
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(fork); (void)hipEventDestroy(join);
     (void)hipStreamDestroy(s0); (void)hipStreamDestroy(s1);
+    return MMISS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fp8 kernels in isolation
+extern "C" int mmiss_dbg_quantize_weights_fp8(int device, void* hip_stream, const void* w_bf16, void* w8, float* scale,
+                                              int32_t N, int32_t K) {
+    if (!w_bf16 || !w8 || !scale || N <= 0 || K <= 0 || (K % 4)) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_quantize_weights_fp8: bad argument");
+    MM_TRY(mmiss_use_device(device));
+    hipLaunchKernelGGL(quantize_weights_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       reinterpret_cast<const uint16_t*>(w_bf16), reinterpret_cast<uint8_t*>(w8), scale, N, K);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_dbg_layernorm_mxfp8(int device, void* hip_stream, const float* x, const float* gamma, const float* beta,
+                                         void* out8, void* out_scale, int32_t M, int32_t d, float eps) {
+    if (!x || !gamma || !beta || !out8 || !out_scale) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_layernorm_mxfp8: null pointer");
+    MM_TRY(mmiss_use_device(device));
+    return launch_layernorm_mxfp8(reinterpret_cast<hipStream_t>(hip_stream), x, gamma, beta, reinterpret_cast<uint8_t*>(out8),
+                                  reinterpret_cast<uint8_t*>(out_scale), M, d, eps);
+}
+
+extern "C" int mmiss_dbg_gemm8(int device, void* hip_stream, int epi, int bm, const void* A8, const void* As, const void* W8,
+                               const float* wscale, const float* bias, void* out, void* out_scale, int32_t M, int32_t N,
+                               int32_t K) {
+    MM_TRY(mmiss_use_device(device));
+    Gemm8Args g{};
+    g.A = reinterpret_cast<const uint8_t*>(A8); g.As = reinterpret_cast<const uint8_t*>(As); g.ld_as = mx_scale_row_bytes(K);
+    g.W = reinterpret_cast<const uint8_t*>(W8); g.wscale = wscale; g.bias = bias; g.out = out;
+    g.out_scale = reinterpret_cast<uint8_t*>(out_scale); g.ld_os = mx_scale_row_bytes(N);
+    g.M = M; g.N = N; g.K = K; g.ldo = N; g.m_valid = M;
+    return launch_gemm8(reinterpret_cast<hipStream_t>(hip_stream), epi, bm, g);
+}
+
+extern "C" int mmiss_dbg_gemm8_time(int device, int epi, int bm, const void* A8, const void* As, const void* W8,
+                                    const float* wscale, const float* bias, void* out, void* out_scale, int32_t M, int32_t N,
+                                    int32_t K, int32_t iters, float* ms_per_launch) {
+    if (!ms_per_launch || iters <= 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_gemm8_time: bad argument");
+    hipEvent_t e0, e1;
+    MM_TRY(mmiss_use_device(device));
+    MM_HIP(hipEventCreate(&e0));
+    MM_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) MM_TRY(mmiss_dbg_gemm8(device, nullptr, epi, bm, A8, As, W8, wscale, bias, out, out_scale, M, N, K));
+    MM_HIP(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) MM_TRY(mmiss_dbg_gemm8(device, nullptr, epi, bm, A8, As, W8, wscale, bias, out, out_scale, M, N, K));
+    MM_HIP(hipEventRecord(e1, nullptr));
+    MM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / iters;
     return MMISS_OK;
 }

@@ -1,0 +1,414 @@
+// gemm_fp8.h — block-scaled fp8 (OCP e4m3, "MXFP8") MFMA GEMM:  C[M,N] = A8[M,K] * W8[N,K]^T  with fused epilogues.
+//
+// The fp8 encode path of BASELINE.json configs[4] ("ViT-L/14 fp8 MFMA encode"): the QKV, FC1 and FC2 projections of the
+// CLIP towers (HF:modeling_clip.py:293-296,338-350) on v_mfma_scale_f32_16x16x128_f8f6f4 — the only fp8 MFMA form that
+// runs above the bf16 rate on gfx950 (2 x bf16 per clock; the non-scaled fp8 MFMA runs AT the bf16 rate,
+// MI355X_MICROARCH.md "Matrix cores").
+//
+// Number format. Activations are MXFP8: e4m3 bytes plus one E8M0 (power-of-two) scale per (row, 32 consecutive k), which
+// the instruction applies in hardware. Weights are e4m3 with one f32 scale per OUTPUT CHANNEL (amax / 448), applied in the
+// epilogue (their hardware block scales are 1). fp8 keeps 3 mantissa bits at any magnitude, so a power-of-two scale
+// loses nothing against an exact one; what the block scale buys is that the producer of an activation only needs the
+// maximum over the 32-64 columns it holds itself (no row-wide reduction across workgroups).
+//
+// Layouts. A8 [M,K] / W8 [N,K] bytes, K contiguous (nn.Linear is [out,in]): a lane's fragment of the 16x16x128 MFMA is
+// 32 consecutive k of one row = lane group g = lane>>4 holds k = 32g..32g+31 — the same for both operands, so the
+// hardware's k order inside a group never matters. Activation scales As [M][16 * ceil(K/512)] bytes: the scale of
+// (row, k-block b = k/32) sits at byte (b/16)*16 + (b%4)*4 + (b/4)%4, i.e. a 4x4 transpose inside each group of 16 blocks,
+// so that ONE dword per lane = the scales of its lane group for 4 consecutive 128-wide K-tiles (selected by OPSEL).
+//
+// Structure = gemm_bf16.h's BM x 128 tile: a 128-element fp8 K-tile is the same 128 bytes per row as a 64-element bf16
+// K-tile, so the LDS image, the global_load_lds staging, the XOR swizzle and the per-K-tile LDS traffic are identical;
+// each K-tile now carries twice the k and its 4 x JT MFMAs take the cycles of the 8 x JT bf16 ones.
+#pragma once
+#include "common.h"
+#include "gemm_bf16.h"
+
+typedef __attribute__((ext_vector_type(8))) int v8i32;
+
+#define MMISS_EPI8_BIAS_BF16 0        // out bf16 [M,N] = acc * sw[n] + bias[n]                          (QKV)
+#define MMISS_EPI8_QGELU_MXFP8 1      // out e4m3 [M,N] + E8M0 scales = mx(quick_gelu(acc * sw[n] + bias[n]))  (FC1)
+#define MMISS_EPI8_BIAS_RESID_F32 2   // out f32 [M,N] += acc * sw[n] + bias[n]                          (FC2)
+
+struct Gemm8Args {
+    const uint8_t* A;       // e4m3 [M, K]
+    const uint8_t* As;      // E8M0 [M, lds_as] permuted (see header)
+    const uint8_t* W;       // e4m3 [N, K]
+    const float* wscale;    // [N]
+    const float* bias;      // [N]
+    void* out;              // bf16 / e4m3 / f32 [M, ldo]
+    uint8_t* out_scale;     // QGELU_MXFP8: E8M0 [M, ld_os] permuted for the NEXT GEMM (whose K = this N)
+    int M, N, K, ldo, m_valid;
+    int ld_as, ld_os;       // bytes per row of As / out_scale
+    int m_fast;
+};
+
+// bytes per row of a permuted scale array for K columns
+static inline int mx_scale_row_bytes(int K) { return 16 * ((K + 511) / 512); }
+// byte offset of k-block b (= k / 32) inside a permuted scale row
+__host__ __device__ __forceinline__ int mx_scale_offset(int b) { return (b >> 4) * 16 + (b & 3) * 4 + ((b >> 2) & 3); }
+
+// E8M0 byte e such that |amax| * 2^-(e-127) <= 448 (the largest e4m3), and the multiplier 2^-(e-127)
+__device__ __forceinline__ void mx_scale_of(float amax, int& e8, float& inv) {
+    const float r = fmaxf(amax, 1e-30f) * (1.0f / 448.0f);
+    const uint32_t u = __float_as_uint(r);
+    int e = (int)(u >> 23) + ((u & 0x7FFFFFu) != 0);  // ceil(log2(r)) + 127
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    e8 = e;
+    inv = __uint_as_float((uint32_t)(254 - e) << 23);  // 2^(127 - e)
+}
+
+// 4 floats -> 4 e4m3 bytes (round to nearest even; callers keep |v| <= 448)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    int p = 0;
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, p, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (uint32_t)p;
+}
+
+template <int OPSEL>
+__device__ __forceinline__ f32x4 mma8(v8i32 w, v8i32 a, f32x4 c, int a_scales) {
+    // A operand = weight fragment (unit block scales), B operand = activation fragment (scale byte OPSEL of a_scales)
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, a, c, 0, 0, 0, 0x7F7F7F7F, OPSEL, a_scales);
+}
+
+template <int BM, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm8_kernel(Gemm8Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = 128, JT = BM / 32;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, BUF = A_BYTES + W_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nbm = g.M / BM, nbn = g.N / BN;
+    const int wg = xcd_remap(blockIdx.x, nbm * nbn);
+    int bm, bn;
+    tile_order(wg, nbm, nbn, g.m_fast, bm, bn);
+    const uint8_t* Ab = g.A + (size_t)bm * BM * g.K;
+    const uint8_t* Wb = g.W + (size_t)bn * BN * g.K;
+
+    // staging: one wave-instruction = 8 rows x 128 B; slot p of row r holds global chunk p ^ (r & 7) (gemm_bf16.h)
+    const int r_in = lane >> 3, p = lane & 7;
+    const int src_chunk = (p ^ r_in) * 16;  // bytes
+    auto stage = [&](int buf, int kt) {
+        char* sA = smem + buf * BUF;
+        char* sW = sA + A_BYTES;
+        const size_t koff = (size_t)kt * 128 + src_chunk;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const int rowblk = wave * (BM / 32) + i;
+            glds16(Ab + (size_t)(rowblk * 8 + r_in) * g.K + koff, sA + rowblk * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int rowblk = wave * (BN / 32) + i;
+            glds16(Wb + (size_t)(rowblk * 8 + r_in) * g.K + koff, sW + rowblk * 1024);
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[4][JT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = g.K / 128;
+    const int nq = (nt + 3) >> 2;
+    // activation scales of this lane's rows: one dword per 16-row fragment and group of 4 K-tiles
+    const uint8_t* sbase = g.As + (size_t)(bm * BM + wm * (BM / 2) + fr) * g.ld_as + fg * 4;
+    int sc_cur[JT], sc_nxt[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        sc_cur[j] = *reinterpret_cast<const int*>(sbase + (size_t)j * 16 * g.ld_as);
+        sc_nxt[j] = sc_cur[j];
+    }
+
+    auto frag = [&](const char* base, int row) -> v8i32 {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * fg) ^ (row & 7)) << 4));
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * fg + 1) ^ (row & 7)) << 4));
+        v8i32 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return v;
+    };
+    auto mma_tile = [&](int buf, auto opsel_tag) {
+        constexpr int OPSEL = decltype(opsel_tag)::value;
+        const char* sA = smem + buf * BUF;
+        const char* sW = sA + A_BYTES;
+        v8i32 wf[4], af[JT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = frag(sW, wn * 64 + i * 16 + fr);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) af[j] = frag(sA, wm * (BM / 2) + j * 16 + fr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) acc[i][j] = mma8<OPSEL>(wf[i], af[j], acc[i][j], sc_cur[j]);
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int q = 0; q < nq; ++q) {
+        if (q + 1 < nq) {  // next group's scales fly during this group's four K-tiles
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+                sc_nxt[j] = *reinterpret_cast<const int*>(sbase + (size_t)j * 16 * g.ld_as + (size_t)(q + 1) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kt = 4 * q + t;
+            if (kt < nt) {
+                const int cur = kt & 1;  // (t & 1: four tiles per group)
+                if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+                if (t == 0) mma_tile(cur, std::integral_constant<int, 0>{});
+                else if (t == 1) mma_tile(cur, std::integral_constant<int, 1>{});
+                else if (t == 2) mma_tile(cur, std::integral_constant<int, 2>{});
+                else mma_tile(cur, std::integral_constant<int, 3>{});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JT; ++j) sc_cur[j] = sc_nxt[j];
+    }
+
+    // ---------------------------------------------------------------- epilogue (staging buffers are dead: per-wave patches)
+    // acc[i][j][r] = C[m = m0 + j*16 + fr][n = n0 + i*16 + 4*fg + r]
+    const int m0 = bm * BM + wm * (BM / 2), n0 = bn * BN + wn * 64;
+    char* patch = smem + wave * EPI_PATCH_BYTES;
+    const int rrow = lane >> 3, rchunk = lane & 7;
+    f32x4 sw[4], bias[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sw[i] = *reinterpret_cast<const f32x4*>(g.wscale + n0 + i * 16 + 4 * fg);
+        bias[i] = *reinterpret_cast<const f32x4*>(g.bias + n0 + i * 16 + 4 * fg);
+    }
+    f32x4 resid[EPI == MMISS_EPI8_BIAS_RESID_F32 ? JT : 1][2][2];
+    if constexpr (EPI == MMISS_EPI8_BIAS_RESID_F32) {  // all residual rows fetched up front (see gemm_bf16.h)
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    resid[j][rh][ch] = *reinterpret_cast<const f32x4*>(
+                        reinterpret_cast<const float*>(g.out) + (size_t)(m0 + j * 16 + rh * 8 + rrow) * g.ldo + n0 + ch * 32 + rchunk * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        if constexpr (EPI == MMISS_EPI8_BIAS_BF16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 y = acc[i][j] * sw[i] + bias[i];
+                u32x2 pk;
+                pk[0] = pack_bf16x2(y[0], y[1]);
+                pk[1] = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<u32x2*>(patch + fr * 144 + i * 32 + fg * 8) = pk;
+            }
+        } else if constexpr (EPI == MMISS_EPI8_QGELU_MXFP8) {
+            // this lane: 16 of the 64 columns of row fr; the row's other 48 sit in lanes fr+16, fr+32, fr+48
+            f32x4 y[4];
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                y[i] = acc[i][j] * sw[i] + bias[i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[i][r] = quick_gelu(y[i][r]);
+                    amax = fmaxf(amax, fabsf(y[i][r]));
+                }
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 16));
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            int e8;
+            float inv;
+            mx_scale_of(amax, e8, inv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<uint32_t*>(patch + fr * 80 + i * 16 + fg * 4) =
+                    pack_fp8x4(y[i][0] * inv, y[i][1] * inv, y[i][2] * inv, y[i][3] * inv);
+            const int m = m0 + j * 16 + fr;
+            if (fg == 0 && m < g.m_valid) {  // the wave's 64 columns = k-blocks n0/32 and n0/32 + 1 of the next GEMM
+                uint8_t* so = g.out_scale + (size_t)m * g.ld_os;
+                so[mx_scale_offset(n0 >> 5)] = (uint8_t)e8;
+                so[mx_scale_offset((n0 >> 5) + 1)] = (uint8_t)e8;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f32x4*>(patch + fr * 272 + i * 64 + fg * 16) = acc[i][j] * sw[i] + bias[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (EPI == MMISS_EPI8_BIAS_BF16) {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const int row = rh * 8 + rrow, m = m0 + j * 16 + row;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 144 + rchunk * 16);
+                if (m < g.m_valid)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(g.out) + (size_t)m * g.ldo + n0 + rchunk * 8) = v;
+            }
+        } else if constexpr (EPI == MMISS_EPI8_QGELU_MXFP8) {
+            // 16 rows x 64 bytes: 4 lanes x 16 B per row, all 16 rows in one instruction
+            const int row = lane >> 2, c16 = lane & 3, m = m0 + j * 16 + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 80 + c16 * 16);
+            if (m < g.m_valid)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(g.out) + (size_t)m * g.ldo + n0 + c16 * 16) = v;
+        } else {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const int row = rh * 8 + rrow, m = m0 + j * 16 + row;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 272 + ch * 128 + rchunk * 16);
+                    if (m < g.m_valid)
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n0 + ch * 32 + rchunk * 4) =
+                            resid[j][rh][ch] + v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next j
+    }
+}
+
+template <int BM, int EPI>
+static int launch_gemm8_inst(hipStream_t st, const Gemm8Args& g) {
+    constexpr int LDS = 2 * (BM + 128) * 128;
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm8_kernel<BM, EPI>), LDS));
+    const int nwg = (g.M / BM) * (g.N / 128);
+    hipLaunchKernelGGL((gemm8_kernel<BM, EPI>), dim3(nwg), dim3(256), LDS, st, g);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+// g.M must be a multiple of bm (128 / 160 / 192), N of 128, K of 128; rows [m_valid, M) of A8 / As must be readable.
+static int launch_gemm8(hipStream_t st, int epi, int bm, Gemm8Args g) {
+    if (bm == 0) bm = 128;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.M % bm) || (g.N % 128) || (g.K % 128) || !g.A || !g.As || !g.W || !g.wscale ||
+        !g.bias || !g.out || g.ld_as < mx_scale_row_bytes(g.K))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm8: M=%d N=%d K=%d bm=%d ld_as=%d", g.M, g.N, g.K, bm, g.ld_as);
+    if (epi == MMISS_EPI8_QGELU_MXFP8 && (!g.out_scale || g.ld_os < mx_scale_row_bytes(g.N)))
+        MM_FAIL(MMISS_ERR_ARG, "gemm8: the MXFP8 epilogue needs out_scale with >= %d bytes per row", mx_scale_row_bytes(g.N));
+    static const char* names[] = {"gemm_fp8_bias", "gemm_fp8_qgelu_mx", "gemm_fp8_bias_resid"};
+    if (epi < 0 || epi > 2) MM_FAIL(MMISS_ERR_ARG, "gemm8: bad epilogue %d", epi);
+    const int mv = g.m_valid < g.M ? g.m_valid : g.M;
+    const double out_b = epi == MMISS_EPI8_BIAS_BF16 ? 2.0 : (epi == MMISS_EPI8_QGELU_MXFP8 ? 1.0 : 8.0);
+    MM_PROF(names[epi], st, 2.0 * mv * (double)g.N * g.K, (double)mv * g.K + (double)g.N * g.K + out_b * mv * g.N);
+#define GEMM8_CASE(BMV)                                                                                    \
+    case BMV:                                                                                              \
+        if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm8_inst<BMV, MMISS_EPI8_BIAS_BF16>(st, g);       \
+        if (epi == MMISS_EPI8_QGELU_MXFP8) return launch_gemm8_inst<BMV, MMISS_EPI8_QGELU_MXFP8>(st, g);   \
+        return launch_gemm8_inst<BMV, MMISS_EPI8_BIAS_RESID_F32>(st, g);
+    switch (bm) {
+        GEMM8_CASE(128)
+        GEMM8_CASE(160)
+        GEMM8_CASE(192)
+    }
+#undef GEMM8_CASE
+    MM_FAIL(MMISS_ERR_ARG, "gemm8: unsupported tile height %d", bm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight quantisation (once, when the fp8 path is switched on): W bf16 [N,K] -> e4m3 [N,K] + scale[n] = amax_n / 448.
+// One wave per output channel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const uint16_t* __restrict__ Wb, uint8_t* __restrict__ W8,
+                                                                   float* __restrict__ scale, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint16_t* w = Wb + (size_t)n * K;
+    float amax = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(w + k);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16_bits_to_f32(v[0] & 0xffff)), fabsf(bf16_bits_to_f32(v[0] >> 16))),
+                                 fmaxf(fabsf(bf16_bits_to_f32(v[1] & 0xffff)), fabsf(bf16_bits_to_f32(v[1] >> 16)))));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    for (int k = lane * 4; k < K; k += 256) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(w + k);
+        // min(): x * (1 / sc) may land one ulp above 448 for the row maximum itself
+        const float a = fminf(fmaxf(bf16_bits_to_f32(v[0] & 0xffff) * inv, -448.f), 448.f);
+        const float b = fminf(fmaxf(bf16_bits_to_f32(v[0] >> 16) * inv, -448.f), 448.f);
+        const float c = fminf(fmaxf(bf16_bits_to_f32(v[1] & 0xffff) * inv, -448.f), 448.f);
+        const float d = fminf(fmaxf(bf16_bits_to_f32(v[1] >> 16) * inv, -448.f), 448.f);
+        *reinterpret_cast<uint32_t*>(W8 + (size_t)n * K + k) = pack_fp8x4(a, b, c, d);
+    }
+    if (lane == 0) scale[n] = sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm with MXFP8 output (K2 in front of the fp8 QKV / FC1 GEMMs): same statistics as layernorm_kernel
+// (encoder_kernels.h; HF:modeling_clip.py:358-360), the normalised row quantised per 32 columns. One wave per row held in
+// registers: lane l holds columns (i*64 + l)*4 .. +3, so 8 consecutive lanes hold one 32-column block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, uint8_t* __restrict__ out,
+                                                              uint8_t* __restrict__ out_scale, int M, int d, int ld_os,
+                                                              float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const float* xr = x + (size_t)r * d;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = (c < d) ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;  // wave-uniform validity: d % 256 == 0 is not required, d % 32 == 0 is
+        f32x4 y = {0.f, 0.f, 0.f, 0.f};
+        if (c < d) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * gm[e] + bb[e];
+        }
+        float amax = fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3])));
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        int e8;
+        float inv;
+        mx_scale_of(amax, e8, inv);
+        if (c < d) {
+            *reinterpret_cast<uint32_t*>(out + (size_t)r * d + c) = pack_fp8x4(y[0] * inv, y[1] * inv, y[2] * inv, y[3] * inv);
+            if ((lane & 7) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
+        }
+    }
+}
+
+static int launch_layernorm_mxfp8(hipStream_t st, const float* x, const float* gamma, const float* beta, uint8_t* out,
+                                  uint8_t* out_scale, int M, int d, float eps) {
+    if (d > 1024 || (d % 32)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "layernorm_mxfp8: d=%d (need d <= 1024, d %% 32 == 0)", d);
+    MM_PROF("layernorm_mxfp8", st, 8.0 * M * d, (double)M * d * 5);
+    hipLaunchKernelGGL(layernorm_mxfp8_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, beta, out, out_scale, M, d,
+                       mx_scale_row_bytes(d), eps);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}

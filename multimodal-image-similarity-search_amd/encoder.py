@@ -157,7 +157,7 @@ class ClipEncoder:
     """One encoder handle = both towers' weights in HBM + workspaces, on one GPU, one HIP stream."""
 
     def __init__(self, shape: ClipShape = VIT_B32, device: int = 0, max_batch_image: int = 256,
-                 max_batch_text: int = 256):
+                 max_batch_text: int = 256, precision: str = "bf16"):
         self.shape = ClipShape.from_any(shape)
         self.device = int(device)
         self._lib = _lib.load()
@@ -170,6 +170,16 @@ class ClipEncoder:
         _lib.check(self._lib.mmiss_encoder_create(C.byref(cfg), self.device, C.byref(h)))
         self._h = h
         self._finalized = False
+        self.precision = "bf16"
+        if precision != "bf16":
+            self.set_precision(precision)
+
+    def set_precision(self, precision: str) -> None:
+        """"bf16" (default) or "fp8": the QKV / FC1 / FC2 projections on the block-scaled fp8 matrix cores (e4m3 operands,
+        f32 accumulation; mmiss_encoder_set_precision) — BASELINE configs[4]. Same parity bar as bf16: 1 - cos <= 1e-3."""
+        code = {"bf16": _lib.MMISS_PREC_BF16, "fp8": _lib.MMISS_PREC_FP8}[precision]
+        _lib.check(self._lib.mmiss_encoder_set_precision(self._h, code))
+        self.precision = precision
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state: Dict[str, "np.ndarray"]) -> Tuple[int, int]:

@@ -1,0 +1,233 @@
+"""The fp8 encode path (BASELINE.json configs[4] "ViT-L/14 fp8 MFMA encode"; csrc/gemm_fp8.h) on the MI355X.
+
+Kernel level: every fp8 kernel against oracle/fp8_oracle.py — the block-scaled MFMA GEMM on identical operand bytes
+(exact arithmetic up to fp32 accumulation), the MXFP8 LayerNorm and the weight quantiser byte for byte.
+End to end: the towers in fp8 against the fp32 oracle at the north_star tolerance (1 - cos <= 1e-3), per layer through
+the taps, on the reference model's own geometry (LongCLIP ViT-L/14; backend/app/utils.py:16-17)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+COS_TOL = 1e-3
+
+
+def _cos(a, b):
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd import _lib
+    from oracle import fp8_oracle as fo
+
+    return torch, _lib, _lib.load(), fo
+
+
+def _bf16_round(x):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(torch.bfloat16)
+
+
+def test_weight_quantiser_bytes_and_scales(env):
+    torch, _lib, lib, fo = env
+    rng = np.random.default_rng(3)
+    N, K = 300, 1024
+    w = (rng.standard_normal((N, K)) * np.exp(rng.standard_normal((N, 1)))).astype(np.float32) * 0.02
+    w[7] = 0.0
+    wb = _bf16_round(w).cuda()
+    w8 = torch.empty((N, K), dtype=torch.uint8, device="cuda")
+    sc = torch.empty((N,), dtype=torch.float32, device="cuda")
+    _lib.check(lib.mmiss_dbg_quantize_weights_fp8(0, None, wb.data_ptr(), w8.data_ptr(), sc.data_ptr(), N, K))
+    torch.cuda.synchronize()
+    q, s = fo.quantize_weights(wb.float().cpu().numpy())
+    np.testing.assert_array_equal(sc.cpu().numpy(), s)
+    np.testing.assert_array_equal(w8.cpu().numpy(), q)
+
+
+@pytest.mark.parametrize("d", [768, 1024])
+def test_layernorm_mxfp8_matches_restatement(env, d):
+    torch, _lib, lib, fo = env
+    rng = np.random.default_rng(4)
+    M = 133
+    x = (rng.standard_normal((M, d)) * 2 + 0.5).astype(np.float32)
+    x[:, 5] += 40.0                                         # an outlier channel: only its 32-column block pays for it
+    gam = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    xd, gd, bd = (torch.from_numpy(a).cuda() for a in (x, gam, bet))
+    out = torch.zeros((M, d), dtype=torch.uint8, device="cuda")
+    osc = torch.zeros((M, fo.scale_row_bytes(d)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.mmiss_dbg_layernorm_mxfp8(0, None, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+                                             osc.data_ptr(), M, d, 1e-5))
+    torch.cuda.synchronize()
+    mu = x.mean(1, keepdims=True, dtype=np.float64)
+    var = ((x - mu) ** 2).mean(1, keepdims=True, dtype=np.float64)
+    y = (((x - mu) / np.sqrt(var + 1e-5)) * gam + bet).astype(np.float32)
+    q, e = fo.mx_quantize(y, 32)
+    got_e = fo.unpermute_scales(osc.cpu().numpy(), d)
+    got_q = out.cpu().numpy()
+    # the GPU's LayerNorm differs from numpy's in the last float32 bits: a value on a rounding boundary may flip a code
+    assert (got_e == e).mean() > 0.999
+    same = got_e.repeat(32, axis=1) == e.repeat(32, axis=1)
+    assert ((got_q == q) | ~same).mean() > 0.998
+    back = fo.mx_dequantize(got_q, got_e)
+    gmax = np.abs(y).reshape(M, -1, 32).max(axis=2).repeat(32, axis=1)
+    assert (np.abs(back - y) <= gmax * 2.0 ** -4 * 1.01 + 1e-6).all()
+
+
+@pytest.mark.parametrize("epi,bm,M,N,K", [(0, 128, 256, 256, 512), (0, 160, 320, 384, 768), (2, 192, 384, 128, 4096),
+                                          (1, 128, 128, 512, 1024), (1, 160, 480, 256, 768), (2, 128, 128, 256, 128)])
+def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
+    """A8 / W8 random e4m3 bytes, activation block scales spread over 2^-6 .. 2^5: the MFMA result must equal the float64
+    product of the DEQUANTISED operands up to fp32 accumulation — this pins the operand layout, the lane <-> k-block <->
+    scale association and the OPSEL walk through the permuted scale words."""
+    torch, _lib, lib, fo = env
+    rng = np.random.default_rng(100 * epi + bm + K)
+    tab = fo.e4m3_table()
+    ok = np.nonzero(~np.isnan(tab) & (np.abs(tab) <= 32))[0].astype(np.uint8)   # keep products small: no f32 overflow
+    A8 = rng.choice(ok, size=(M, K))
+    W8 = rng.choice(ok, size=(N, K))
+    e = rng.integers(121, 133, size=(M, K // 32)).astype(np.uint8)
+    ws = np.exp2(rng.integers(-8, -2, size=N)).astype(np.float32) * rng.uniform(1, 2, size=N).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    A = fo.mx_dequantize(A8, e)
+    W = fo.e4m3_decode(W8).astype(np.float64)
+    acc = A @ W.T
+    ref = acc * ws[None, :].astype(np.float64) + bias[None, :]
+    absacc = (np.abs(A) @ np.abs(W).T) * ws[None, :]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    A8d, Asd, W8d, wsd, bd = dev(A8), dev(fo.permute_scales(e)), dev(W8), dev(ws), dev(bias)
+    osc = torch.zeros((M, fo.scale_row_bytes(N)), dtype=torch.uint8, device="cuda")
+    if epi == 0:
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    elif epi == 1:
+        out = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    else:
+        x0 = rng.standard_normal((M, N)).astype(np.float32)
+        out = dev(x0)
+    _lib.check(lib.mmiss_dbg_gemm8(0, None, epi, bm, A8d.data_ptr(), Asd.data_ptr(), W8d.data_ptr(), wsd.data_ptr(),
+                                   bd.data_ptr(), out.data_ptr(), osc.data_ptr(), M, N, K))
+    torch.cuda.synchronize()
+    tol_acc = absacc * K * 2.0 ** -23 + 1e-6                # fp32 accumulation of K terms
+    if epi == 0:
+        got = out.float().cpu().numpy()
+        assert (np.abs(got - ref) <= tol_acc + np.abs(ref) * 2.0 ** -8).all()      # + the bf16 rounding of the output
+    elif epi == 2:
+        got = out.cpu().numpy()
+        assert (np.abs(got - (ref + x0)) <= tol_acc + 1e-5 * (np.abs(ref) + np.abs(x0))).all()
+    else:
+        y = ref * (1.0 / (1.0 + np.exp(-1.702 * ref)))     # QuickGELU, HF:activations.py:117-123
+        got_e = fo.unpermute_scales(osc.cpu().numpy(), N)
+        back = fo.mx_dequantize(out.cpu().numpy(), got_e)
+        g64 = np.abs(y).reshape(M, -1, 64).max(axis=2)
+        e_ref, _ = fo.e8m0_for(g64.astype(np.float32))
+        assert (got_e[:, ::2] == got_e[:, 1::2]).all()                              # one scale per 64 columns
+        assert (np.abs(got_e[:, ::2].astype(int) - e_ref.astype(int)) <= 1).all() and (got_e[:, ::2] == e_ref).mean() > 0.99
+        gmax = g64.repeat(64, axis=1)
+        assert (np.abs(back - y) <= gmax * 2.0 ** -4 * 1.02 + tol_acc * 2 + 1e-6).all()
+
+
+def _fp8_vs_bf16_vs_oracle(shape, seed, B_img, B_txt, T):
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    W = co.init_weights(shape, seed=seed)
+    rng = np.random.Generator(np.random.Philox(seed + 1))
+    px = rng.standard_normal((B_img, 3, shape.v_image, shape.v_image), dtype=np.float32)
+    ids = co.synthetic_text_ids(B_txt, T, shape.t_vocab, shape.eos_token_id, seed=seed + 2)
+    out = {}
+    for prec in ("bf16", "fp8"):
+        enc = ClipEncoder(ClipShape.from_any(shape), max_batch_image=B_img, max_batch_text=B_txt, precision=prec)
+        enc.load_state_dict(W)
+        out[prec] = (enc.encode_image(px), enc.encode_text(ids, trim_padding=False))
+        enc.close()
+    return W, px, ids, out, co
+
+
+def test_longclip_l14_geometry_fp8_vs_oracle(env):
+    """The reference model's own geometry (d = 1024 / 16 heads / T = 257 vision, d = 768 / T = 248 text) at 4 layers:
+    8 images = 2056 rows and 8 texts = 1984 rows, both above the fp8 threshold. fp8 and bf16 against the fp32 oracle."""
+    import dataclasses
+    from mmiss_amd import _lib
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.LONGCLIP_L14, v_layers=4, t_layers=4, t_vocab=2000, eos_token_id=1999)
+    (W, px, ids, out, co), kern = _with_kernels(lambda: _fp8_vs_bf16_vs_oracle(s, 31, 8, 8, 248))
+    assert kern.get("gemm_fp8_bias", 0) > 0 and kern.get("gemm_fp8_qgelu_mx", 0) > 0 and kern.get("gemm_fp8_bias_resid", 0) > 0, kern
+    ref_i, ref_t = co.embed_images(px, W, s), co.embed_texts(ids, W, s)
+    for prec in ("bf16", "fp8"):
+        di, dt = 1 - _cos(out[prec][0], ref_i), 1 - _cos(out[prec][1], ref_t)
+        print(prec, "image 1-cos max", di.max(), "text 1-cos max", dt.max())
+        assert di.max() < COS_TOL and dt.max() < COS_TOL, (prec, di, dt)
+
+
+def _with_kernels(fn):
+    from mmiss_amd import _lib
+
+    _lib.prof_filter(None, 1)
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    try:
+        r = fn()
+    finally:
+        _lib.prof_enable(False)
+    return r, {p["kernel"]: p["launches"] for p in _lib.prof_read()}
+
+
+def test_fp8_residual_stream_layer_by_layer(env):
+    """Per-layer error of the fp8 path through mmiss_encoder_tap on a d = 1024 tower (6 layers, T = 65, 32 images =
+    2080 rows): the relative error of the residual stream against the fp32 oracle must stay bounded (< 3 % of the layer's
+    largest magnitude, the bar of the bf16 path) — it must not compound layer over layer."""
+    import dataclasses
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.TINY, v_hidden=1024, v_heads=16, v_mlp=4096, v_layers=6, v_patch=28, v_image=224)
+    W = co.init_weights(s, seed=41)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=32, max_batch_text=4, precision="fp8")
+    enc.record_taps(True)
+    enc.load_state_dict(W)
+    rng = np.random.Generator(np.random.Philox(42))
+    px = rng.standard_normal((32, 3, 224, 224), dtype=np.float32)
+    out = enc.encode_image(px)
+    taps = {}
+    ref = co.l2_normalize(co.image_features(px, W, s, taps))
+    T, d = s.v_tokens, s.v_hidden
+    rel = []
+    for l in range(s.v_layers + 1):
+        got = enc.tap(0, l, 32 * T * d).reshape(32, T, d)
+        rel.append(float(np.abs(got - taps[l]).max() / np.abs(taps[l]).max()))
+    print("fp8 per-layer max rel err", [round(r, 4) for r in rel])
+    assert max(rel) < 0.03, rel
+    assert (1 - _cos(out, ref)).max() < COS_TOL
+    enc.close()
+
+
+def test_small_calls_fall_back_to_bf16_kernels(env):
+    """Below 1024 token rows a call stays on the bf16 kernels (weight-streaming / split-K paths the fp8 tile kernel does
+    not have): one image through an fp8-enabled handle equals the bf16 handle bit for bit."""
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = co.TINY
+    W = co.init_weights(s, seed=0)
+    rng = np.random.Generator(np.random.Philox(7))
+    px = rng.standard_normal((4, 3, s.v_image, s.v_image), dtype=np.float32)
+    outs = []
+    for prec in ("bf16", "fp8"):
+        enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=4, max_batch_text=4, precision=prec)
+        enc.load_state_dict(W)
+        outs.append(enc.encode_image(px))
+        enc.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
+    late = ClipEncoder(ClipShape.from_any(s), max_batch_image=4, max_batch_text=4)
+    late.load_state_dict(W)
+    late.set_precision("fp8")          # after finalize: weights are quantised then
+    np.testing.assert_array_equal(late.encode_image(px), outs[0])
+    with pytest.raises(KeyError):
+        late.set_precision("int4")
+    late.close()
