@@ -11,11 +11,15 @@
 // loses nothing against an exact one; what the block scale buys is that the producer of an activation only needs the
 // maximum over the 32-64 columns it holds itself (no row-wide reduction across workgroups).
 //
-// Layouts. A8 [M,K] / W8 [N,K] bytes, K contiguous (nn.Linear is [out,in]): a lane's fragment of the 16x16x128 MFMA is
-// 32 consecutive k of one row = lane group g = lane>>4 holds k = 32g..32g+31 — the same for both operands, so the
-// hardware's k order inside a group never matters. Activation scales As [M][16 * ceil(K/512)] bytes: the scale of
+// Layouts. A8 [M,K] / W8 [N,K] bytes, K contiguous (nn.Linear is [out,in]). A lane's fragment of the 16x16x128 MFMA is 32
+// bytes of one row: lane group g = lane>>4 holds k = 16g..16g+15 in registers 0-3 and k = 64+16g..64+16g+15 in registers
+// 4-7 (both operands alike); the E8M0 scale of k-block c = k/32 is read from lane group c. Activation scales As [M][16 * ceil(K/512)] bytes: the scale of
 // (row, k-block b = k/32) sits at byte (b/16)*16 + (b%4)*4 + (b/4)%4, i.e. a 4x4 transpose inside each group of 16 blocks,
 // so that ONE dword per lane = the scales of its lane group for 4 consecutive 128-wide K-tiles (selected by OPSEL).
+//
+// Accumulation (measured, tools/fp8_probe.py): inside one instruction the 128 products of a row are aligned to the largest
+// and summed with ~13 significant bits (448 + 511 * 2^-6 -> 455.875, not 455.984; worst |error| / sum|terms| 1.5e-4),
+// between instructions in f32. That is an order of magnitude below the e4m3 rounding of the operands themselves.
 //
 // Structure = gemm_bf16.h's BM x 128 tile: a 128-element fp8 K-tile is the same 128 bytes per row as a 64-element bf16
 // K-tile, so the LDS image, the global_load_lds staging, the XOR swizzle and the per-K-tile LDS traffic are identical;
@@ -126,8 +130,11 @@ __global__ __launch_bounds__(256, 2) void gemm8_kernel(Gemm8Args g) {
     }
 
     auto frag = [&](const char* base, int row) -> v8i32 {
-        const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * fg) ^ (row & 7)) << 4));
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(base + row * 128 + (((2 * fg + 1) ^ (row & 7)) << 4));
+        // registers 0-3 = k 16g .. 16g+15, registers 4-7 = k 64+16g .. 64+16g+15 of the 128-wide K-tile (the instruction is
+        // two K = 64 halves); hardware k-block c = k 32c .. 32c+31 takes its scale from lane group c (measured:
+        // tools/fp8_probe.py — with 32 contiguous k per lane the data was right and the scale association wrong)
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + ((fg ^ (row & 7)) << 4));
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(base + row * 128 + (((4 + fg) ^ (row & 7)) << 4));
         v8i32 v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
