@@ -1,5 +1,6 @@
 // runtime.hip — error strings, device selection and per-kernel HIP-event timing of libmmiss.
 #include "common.h"
+#include <atomic>
 #include <map>
 
 // ------------------------------------------------------------------ errors
@@ -83,7 +84,12 @@ int mmiss_ensure_dyn_lds(const void* kernel, int lds) {
     return MMISS_OK;
 }
 
+// Options exist for tests and A/B experiments; a production process never sets one. Until the first
+// mmiss_dbg_set_option call every lookup is one relaxed atomic load (no mutex, no std::string): the launch paths ask for
+// ~25 options per encode on a single-request path that is already dispatch-bound.
+static std::atomic<bool> g_opts_any{false};
 int mmiss_option(const char* key, int dflt) {
+    if (!g_opts_any.load(std::memory_order_acquire)) return dflt;
     std::lock_guard<std::mutex> lk(g_opt_mu);
     auto it = g_opts.find(key);
     return it == g_opts.end() ? dflt : it->second;
@@ -92,6 +98,7 @@ extern "C" int mmiss_dbg_set_option(const char* key, int value) {
     if (!key) MM_FAIL(MMISS_ERR_ARG, "null option key");
     std::lock_guard<std::mutex> lk(g_opt_mu);
     g_opts[key] = value;
+    g_opts_any.store(true, std::memory_order_release);
     return MMISS_OK;
 }
 
