@@ -17,6 +17,7 @@ struct mmiss_index {
     DevBuf stage, qn, qs, qstage, lists_s, lists_r, lists2_s, lists2_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, gmax;
     // exactness guard + widen pass (see "exactness contract" above mmiss_index_query)
     DevBuf flags, nflag_d, qmap, qmap64, qs2, cand2, cur2_s, cur2_r;
+    DevBuf seed_s, seed_r, fcnt, fbuf_s, fbuf_g;  // threshold-filtered selection (Q > 128)
     int32_t* nflag_h = nullptr;  // pinned
     int64_t stat_queries = 0, stat_flagged = 0, stat_rounds = 0, stat_pages = 0;
     hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
@@ -568,6 +569,8 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         MM_TRY(ix->nflag_d.ensure(64));
         MM_HIP(hipMemsetAsync(ix->nflag_d.p, 0, 4, st));
     }
+    const int32_t* ovf_cnt = nullptr;  // threshold-filtered selection: per-query append counts and their capacity
+    int ovf_cap = 0;
     if (N == 0) {
         MM_HIP(hipMemsetAsync(ix->cand.p, 0xff, (size_t)Q * ncand * 4, st));  // all -1
     } else if (dense) {
@@ -576,21 +579,35 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         const bool big = Q >= mmiss_option("score_big_min_q", 129);
         const int64_t Npad = round_up(N, big ? 256 : 128);
         const int Mq = (int)round_up(Q, big ? 256 : 128);
-        const int ng = (int)(Npad / 16);
+        // Threshold-filtered selection (Q > 128, index of at least 128 tiles): the first 1/16 of the rows (the SAMPLE) goes
+        // through the dense path — group maxima to HBM, select, merge — which yields each query's k' best sample groups and
+        // their k'-th score tau_q. tau_q is a lower bound of the final k'-th best group maximum, so over the other 15/16 of
+        // the rows the strip kernel only APPENDS the groups reaching tau_q (~15 k' per query) to a per-query candidate
+        // list; one merge over {sample list} + {appended} gives exactly the k' groups the dense path selects. The Q x N/16
+        // group-maximum matrix (2.56 GB at Q = 1024, N = 10M) is neither written nor read back. A query whose list overflows
+        // (a tau_q far below the final one: sorted or clustered data) is handed to the widen pass by the guard.
+        const int64_t nbn = Npad / 256;
+        const int64_t ns_tiles = std::max<int64_t>(16, nbn / 16);
+        const bool filtered = big && nbn >= 128 && mmiss_option("score_filter", 1) != 0;
+        const int64_t Ndense = filtered ? ns_tiles * 256 : Npad;   // rows whose group maxima are materialised
+        const int ng = (int)(Ndense / 16);
         MM_TRY(ix->gmax.ensure((size_t)Mq * ng * 4));
         GemmEpi ep{};
         ep.out = ix->gmax.p; ep.ldo = ng; ep.m_valid = Q; ep.p0 = (int)N; ep.m_fast = 1;
+        int strip = 1;
+        if (big) {
+            // consecutive N-tiles per workgroup: long enough to amortise the pipeline fill, short enough to leave
+            // >= 8 workgroups per CU for balance
+            const int64_t tiles = nbn * (Mq / 256);
+            strip = (int)std::min<int64_t>(32, std::max<int64_t>(1, tiles / 2048));
+            const int forced = mmiss_option("score_strip", 0);
+            if (forced > 0) strip = forced;
+        }
         {
-            MM_PROF("score_gemm_f16", st, 2.0 * Q * (double)N * D, (double)N * D * 2);
-            if (big) {
-                // consecutive N-tiles per workgroup: long enough to amortise the pipeline fill, short enough to leave
-                // >= 8 workgroups per CU for balance
-                const int64_t tiles = (Npad / 256) * (Mq / 256);
-                int strip = (int)std::min<int64_t>(32, std::max<int64_t>(1, tiles / 2048));
-                const int forced = mmiss_option("score_strip", 0);
-                if (forced > 0) strip = forced;
-                MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip)));
-            }
+            MM_PROF(filtered ? "score_gemm_f16_sample" : "score_gemm_f16", st, 2.0 * Q * (double)std::min<int64_t>(N, Ndense) * D,
+                    (double)std::min<int64_t>(N, Ndense) * D * 2);
+            if (big)
+                MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Ndense, D, strip)));
             else
                 MM_TRY((launch_gemm_inst<_Float16, 128, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D)));
         }
@@ -612,6 +629,35 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         MergeArgs m{};
         m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
         m.L = splits; m.Q = Q; m.kp = kp;
+        if (filtered) {
+            const int cap = mmiss_option("score_filter_cap", 2048);
+            MM_TRY(ix->seed_s.ensure((size_t)Mq * kp * 4));
+            MM_TRY(ix->seed_r.ensure((size_t)Mq * kp * 4));
+            MM_TRY(ix->fcnt.ensure((size_t)Mq * 4));
+            MM_TRY(ix->fbuf_s.ensure((size_t)Mq * cap * 4));
+            MM_TRY(ix->fbuf_g.ensure((size_t)Mq * cap * 4));
+            {   // the sample's k' best groups per query WITH their scores: seed of the final merge, source of tau_q
+                MergeArgs m1 = m;
+                m1.lists_per_block = splits; m1.out_s = ix->seed_s.as<float>(); m1.out_r = ix->seed_r.as<int32_t>();
+                MM_PROF("merge_lists", st, 0.0, (double)splits * Q * kp * 8);
+                hipLaunchKernelGGL(merge_lists_kernel, dim3(Q, 1), dim3(256), 0, st, m1);
+                MM_HIP(hipGetLastError());
+            }
+            MM_HIP(hipMemsetAsync(ix->fcnt.p, 0, (size_t)Mq * 4, st));
+            StripFilter flt{};
+            flt.tau = ix->seed_s.as<float>() + (kp - 1); flt.tau_stride = kp;
+            flt.cnt = ix->fcnt.as<int32_t>(); flt.buf_s = ix->fbuf_s.as<float>(); flt.buf_g = ix->fbuf_g.as<int32_t>();
+            flt.cap = cap; flt.bn_begin = (int)ns_tiles;
+            {
+                MM_PROF("score_gemm_f16", st, 2.0 * Q * (double)(N - Ndense) * D, (double)(N - Ndense) * D * 2);
+                MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
+            }
+            m.in_s = ix->seed_s.as<float>(); m.in_r = ix->seed_r.as<int32_t>(); m.L = 1;
+            m.flat_s = ix->fbuf_s.as<float>(); m.flat_r = ix->fbuf_g.as<int32_t>(); m.flat_cnt = ix->fcnt.as<int32_t>();
+            m.flat_cap = cap;
+            ovf_cnt = ix->fcnt.as<int32_t>();
+            ovf_cap = cap;
+        }
         m.cand = ix->cand.as<int32_t>(); m.cand_stride = ncand; m.page_off = 0;
         m.cur_s = ix->cur_s.as<float>(); m.cur_r = ix->cur_r.as<int32_t>();  // k'-th group maximum
         MM_TRY(launch_merge(ix, st, m));
@@ -653,6 +699,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
             r.tau = ix->cur_s.as<float>(); r.eps = guard_eps(ix);
             r.flags = ix->flags.as<int32_t>(); r.nflag = ix->nflag_d.as<int32_t>();
             r.force_flag = mmiss_option("guard_force", 0);
+            r.ovf_cnt = ovf_cnt; r.ovf_cap = ovf_cap;
         }
         MM_TRY(launch_rerank(ix, st, r, Q));
     }

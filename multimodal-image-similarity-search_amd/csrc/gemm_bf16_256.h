@@ -189,9 +189,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ 
 // the current one, the group-max epilogue (registers and global stores only, no LDS) runs while those loads fly, and
 // the accumulators are simply zeroed. Sibling workgroups (the other M-tiles of the same strip) are adjacent in launch
 // order, so the index rows still come from HBM once and from L2 for the rest.
-template <typename IN>
+// FILTER = true (the second pass of the threshold-filtered selection, api_index.hip): instead of writing every group maximum,
+// a lane APPENDS (maximum, group) to its query's candidate list when the maximum reaches the query's threshold tau[q] — the
+// k'-th best group maximum of a sample of the index, a lower bound of the final k'-th best, so every group of the true
+// top-k' passes. Appends are rare (~k' / sample fraction per query over the whole pass): the score matrix never touches
+// HBM. Tiles [bn_begin, N/256) only (the sample owns the tiles before).
+struct StripFilter {
+    const float* tau;     // threshold of query m at tau[m * tau_stride] (-inf: keep everything)
+    int tau_stride;
+    int32_t* cnt;         // [M] entries appended so far (may run past cap: the excess is dropped and the query re-done)
+    float* buf_s;         // [M][cap]
+    int32_t* buf_g;       // [M][cap] group ids
+    int cap;
+    int bn_begin;
+};
+
+template <typename IN, bool FILTER = false>
 __global__ __launch_bounds__(512, 2) void gemm256_strip_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M,
-                                                               int N, int K, int strip, GemmEpi ep) {
+                                                               int N, int K, int strip, GemmEpi ep, StripFilter flt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename MfmaIn<IN>::frag frag;
     const int tid = threadIdx.x;
@@ -200,10 +215,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_strip_kernel(const IN* __restr
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int nbm = M >> 8, nbn = N >> 8;
-    const int nstrips = (nbn + strip - 1) / strip;
+    const int bn_begin = FILTER ? flt.bn_begin : 0;
+    const int nstrips = (nbn - bn_begin + strip - 1) / strip;
     const int wg = xcd_remap(blockIdx.x, nbm * nstrips);
     const int sidx = wg / nbm, bm = wg - sidx * nbm;   // m fastest: the M-tiles of one strip run side by side
-    const int bn0 = sidx * strip;
+    const int bn0 = bn_begin + sidx * strip;
     const int ntiles = (nbn - bn0 < strip) ? nbn - bn0 : strip;
     const IN* Ab = A + (size_t)bm * 256 * K;
     const IN* Wb = W + (size_t)bn0 * 256 * K;
@@ -251,6 +267,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_strip_kernel(const IN* __restr
         for (int s = 0; s < 2; ++s) w_off[nf][s] = row * 128 + (((4 * s + fg) ^ (row & 7)) << 4);
     }
 
+    float tau_r[8];  // FILTER: thresholds of this lane's 8 queries
+    if constexpr (FILTER) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = bm * 256 + wm * 128 + j * 16 + fr;
+            tau_r[j] = (m < ep.m_valid) ? flt.tau[(size_t)m * flt.tau_stride] : INFINITY;
+        }
+    }
     // stream positions of t+1 and t+2, advanced once per K-tile (no division in the loop)
     int kt1 = (nt > 1) ? 1 : 0, tile1 = (nt > 1) ? 0 : 1;
     int kt2 = (nt > 2) ? 2 : (2 % nt), tile2 = 2 / nt;
@@ -308,7 +332,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_strip_kernel(const IN* __restr
                         acc[i][j][r] = 0.f;
                     }
                 const int m = bm * 256 + wm * 128 + j * 16 + fr;
-                if (m < ep.m_valid) out[(size_t)m * ep.ldo + g] = mx;
+                if constexpr (FILTER) {
+                    if (mx >= tau_r[j] && mx > -INFINITY) {  // (tau_r = +inf for pad queries; -inf maxima = all-pad groups)
+                        const int pos = atomicAdd(flt.cnt + m, 1);
+                        if (pos < flt.cap) {
+                            flt.buf_s[(size_t)m * flt.cap + pos] = mx;
+                            flt.buf_g[(size_t)m * flt.cap + pos] = g;
+                        }
+                    }
+                } else {
+                    if (m < ep.m_valid) out[(size_t)m * ep.ldo + g] = mx;
+                }
             }
             kt = 0;
             ++tile;
@@ -323,14 +357,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_strip_kernel(const IN* __restr
 
 template <typename IN>
 static int launch_gemm256_strip(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
-                                int strip) {
+                                int strip, const StripFilter* flt = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % GEMM_BK) || strip < 1)
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256_strip: M=%d N=%d K=%d strip=%d", M, N, K, strip);
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256_strip_kernel<IN>), G256_LDS));
     const int nbn = N / 256;
-    const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
-    hipLaunchKernelGGL((gemm256_strip_kernel<IN>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
-                       reinterpret_cast<const IN*>(W), M, N, K, strip, ep);
+    if (flt) {
+        if (flt->bn_begin < 0 || flt->bn_begin >= nbn || !flt->tau || !flt->cnt || !flt->buf_s || !flt->buf_g || flt->cap <= 0)
+            MM_FAIL(MMISS_ERR_ARG, "gemm256_strip: bad filter");
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256_strip_kernel<IN, true>), G256_LDS));
+        const int nwg = (M / 256) * ((nbn - flt->bn_begin + strip - 1) / strip);
+        hipLaunchKernelGGL((gemm256_strip_kernel<IN, true>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                           reinterpret_cast<const IN*>(W), M, N, K, strip, ep, *flt);
+    } else {
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256_strip_kernel<IN, false>), G256_LDS));
+        const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
+        hipLaunchKernelGGL((gemm256_strip_kernel<IN, false>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                           reinterpret_cast<const IN*>(W), M, N, K, strip, ep, StripFilter{});
+    }
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }

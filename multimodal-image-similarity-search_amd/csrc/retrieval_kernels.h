@@ -433,6 +433,11 @@ struct MergeArgs {
     int lists_per_block;
     float* out_s;
     int32_t* out_r;
+    // threshold-filtered selection: besides the L lists, min(flat_cnt[q], flat_cap) loose (score, id) entries per query
+    const float* flat_s;     // [Q][flat_cap]
+    const int32_t* flat_r;
+    const int32_t* flat_cnt; // [Q]
+    int flat_cap;
 };
 
 // A wave streams 64 - kp entries per step, so a list of <= kp (<= 32) entries can never outgrow its 64-slot
@@ -450,7 +455,12 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
     const int l_begin = a.out_s ? blockIdx.y * a.lists_per_block : 0;
     int l_end = a.out_s ? l_begin + a.lists_per_block : a.L;
     if (l_end > a.L) l_end = a.L;
-    const int64_t total = (int64_t)(l_end > l_begin ? l_end - l_begin : 0) * kp;
+    const int64_t list_total = (int64_t)(l_end > l_begin ? l_end - l_begin : 0) * kp;
+    int64_t total = list_total;
+    if (a.flat_s) {
+        const int c = a.flat_cnt[q];
+        total += c < a.flat_cap ? c : a.flat_cap;
+    }
     // A wave takes NL = 64 - kp entries per step (its 64-slot buffer holds at most kp survivors + NL newcomers) and loads
     // the next step's entries before it files the current ones, so the global-load latency overlaps the LDS work.
     const int NL = 64 - kp;
@@ -459,11 +469,17 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
         r = -1;
         const int64_t e = e0 + lane;
         if (lane < NL && e < total) {
-            const int64_t l = l_begin + e / kp;
-            const int slot = (int)(e % kp);
-            const size_t o = ((size_t)l * a.Q + q) * kp + slot;
-            s = a.in_s[o];
-            r = a.in_r[o];
+            if (e < list_total) {
+                const int64_t l = l_begin + e / kp;
+                const int slot = (int)(e % kp);
+                const size_t o = ((size_t)l * a.Q + q) * kp + slot;
+                s = a.in_s[o];
+                r = a.in_r[o];
+            } else {
+                const size_t o = (size_t)q * a.flat_cap + (size_t)(e - list_total);
+                s = a.flat_s[o];
+                r = a.flat_r[o];
+            }
         }
     };
     float s, sn;
@@ -560,6 +576,9 @@ struct RerankArgs {
     int32_t* flags;
     int32_t* nflag;
     int force_flag;         // tests: flag every query whose candidate list was full
+    // threshold-filtered selection: a query whose candidate list overflowed (ovf_cnt[q] > ovf_cap) lost candidates: flag it
+    const int32_t* ovf_cnt;
+    int ovf_cap;
 };
 
 template <typename T>
@@ -637,6 +656,7 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
             const float t = a.tau ? a.tau[b] : SCAN_NEG_INF;
             if (t > SCAN_NEG_INF) {  // stage 1 left rows out: every one of them has an approximate score <= t
                 if (nvalid < k_eff || a.force_flag) flag = 1;
+                else if (a.ovf_cnt && a.ovf_cnt[q] > a.ovf_cap) flag = 1;
                 else {
                     const double ck = 1.0 - (double)sd[k_eff - 1];  // k-th canonical score (its float rounding is inside eps)
                     if (!(ck - (double)t > a.eps)) flag = 1;

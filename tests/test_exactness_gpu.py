@@ -153,3 +153,39 @@ def test_guard_stays_quiet_on_random_data(mods):
     assert st["queries"] == 1 + 16 + 256 + 700
     assert st["widened"] <= 2, st           # expectation ~4e-5 per query
     idx.close()
+
+
+def test_filtered_selection_overflow_is_handed_to_the_widen_pass(mods):
+    """Q > 128 over >= 128 index tiles takes the threshold-filtered selection: tau_q comes from the first 1/16 of the rows.
+    Here the rows get MORE similar to the first queries the later they come, so tau_q is far too low, their candidate lists
+    overflow, and the guard must route exactly those queries through the widen pass; every query still equals the oracle.
+    Then the same with a deliberately tiny list capacity on random data, and with the filter switched off."""
+    FlatIndex, ro, _lib = mods
+    N, D, Q, k = 60000, 256, 200, 10
+    c = _randn(N, D, seed=71)
+    q = _randn(Q, D, seed=72)
+    ramp = (np.arange(N, dtype=np.float32) / N)[:, None]
+    for j in range(3):
+        sel = slice(j, N, 3)                      # every third row drifts towards query j, more and more
+        c[sel] += 6.0 * ramp[sel] * _unit(q[j])[None, :] * np.sqrt(D)
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(D, "f16", capacity=N)
+    idx.add(c, labels)
+    stored = ro.normalize_rows(c, "f16")
+    sub = np.concatenate([np.arange(6), np.arange(6, Q, 23)])
+    lab, dist, cnt = idx.query(q, k)
+    st = idx.guard_stats()
+    assert st["widened"] >= 3, st                 # the three drifting queries overflowed
+    ol, od, oc = ro.query(q[sub], stored, labels, k)
+    np.testing.assert_array_equal(lab[sub], ol)
+    np.testing.assert_array_equal(dist[sub].view(np.uint32), od.view(np.uint32))
+    full = (lab.copy(), dist.copy())
+    for opt, val in (("score_filter_cap", 8), ("score_filter", 0)):
+        _lib.set_option(opt, val)
+        try:
+            l2, d2, _ = idx.query(q, k)
+        finally:
+            _lib.set_option(opt, 2048 if opt == "score_filter_cap" else 1)
+        np.testing.assert_array_equal(l2, full[0])
+        np.testing.assert_array_equal(d2.view(np.uint32), full[1].view(np.uint32))
+    idx.close()
