@@ -579,16 +579,19 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         const bool big = Q >= mmiss_option("score_big_min_q", 129);
         const int64_t Npad = round_up(N, big ? 256 : 128);
         const int Mq = (int)round_up(Q, big ? 256 : 128);
-        // Threshold-filtered selection (Q > 128, index of at least 128 tiles): the first 1/16 of the rows (the SAMPLE) goes
+        // Threshold-filtered selection (Q > 128, index of at least 128 tiles): the first 1/32 of the rows (the SAMPLE) goes
         // through the dense path — group maxima to HBM, select, merge — which yields each query's k' best sample groups and
-        // their k'-th score tau_q. tau_q is a lower bound of the final k'-th best group maximum, so over the other 15/16 of
-        // the rows the strip kernel only APPENDS the groups reaching tau_q (~15 k' per query) to a per-query candidate
+        // their k'-th score tau_q. tau_q is a lower bound of the final k'-th best group maximum, so over the other 31/32 of
+        // the rows the strip kernel only APPENDS the groups reaching tau_q (~31 k' per query) to a per-query candidate
         // list; one merge over {sample list} + {appended} gives exactly the k' groups the dense path selects. The Q x N/16
         // group-maximum matrix (2.56 GB at Q = 1024, N = 10M) is neither written nor read back. A query whose list overflows
         // (a tau_q far below the final one: sorted or clustered data) is handed to the widen pass by the guard.
+        // It costs four extra small launches (~35 us), so it is taken when the matrix it avoids is worth more: from
+        // Q x N = 10^9 scores (256 MB of group maxima written and read back). Option score_filter: 0 never, 2 whenever possible.
         const int64_t nbn = Npad / 256;
-        const int64_t ns_tiles = std::max<int64_t>(16, nbn / 16);
-        const bool filtered = big && nbn >= 128 && mmiss_option("score_filter", 1) != 0;
+        const int64_t ns_tiles = std::max<int64_t>(16, nbn / 32);
+        const int filter_opt = mmiss_option("score_filter", 1);
+        const bool filtered = big && nbn >= 128 && filter_opt != 0 && (filter_opt == 2 || (double)Mq * (double)Npad >= 1e9);
         const int64_t Ndense = filtered ? ns_tiles * 256 : Npad;   // rows whose group maxima are materialised
         const int ng = (int)(Ndense / 16);
         MM_TRY(ix->gmax.ensure((size_t)Mq * ng * 4));

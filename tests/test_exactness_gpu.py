@@ -173,19 +173,25 @@ def test_filtered_selection_overflow_is_handed_to_the_widen_pass(mods):
     idx.add(c, labels)
     stored = ro.normalize_rows(c, "f16")
     sub = np.concatenate([np.arange(6), np.arange(6, Q, 23)])
-    lab, dist, cnt = idx.query(q, k)
+    _lib.set_option("score_filter", 2)            # (by default only from Q x N = 1e9 scores)
+    try:
+        lab, dist, cnt = idx.query(q, k)
+    finally:
+        _lib.set_option("score_filter", 1)
     st = idx.guard_stats()
     assert st["widened"] >= 3, st                 # the three drifting queries overflowed
     ol, od, oc = ro.query(q[sub], stored, labels, k)
     np.testing.assert_array_equal(lab[sub], ol)
     np.testing.assert_array_equal(dist[sub].view(np.uint32), od.view(np.uint32))
     full = (lab.copy(), dist.copy())
-    for opt, val in (("score_filter_cap", 8), ("score_filter", 0)):
-        _lib.set_option(opt, val)
+    for opts in ({"score_filter": 2, "score_filter_cap": 8}, {"score_filter": 0}):
+        for o, v in opts.items():
+            _lib.set_option(o, v)
         try:
             l2, d2, _ = idx.query(q, k)
         finally:
-            _lib.set_option(opt, 2048 if opt == "score_filter_cap" else 1)
+            _lib.set_option("score_filter", 1)
+            _lib.set_option("score_filter_cap", 2048)
         np.testing.assert_array_equal(l2, full[0])
         np.testing.assert_array_equal(d2.view(np.uint32), full[1].view(np.uint32))
     idx.close()

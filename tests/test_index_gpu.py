@@ -122,8 +122,11 @@ def test_score_gemm_strips(mods, strip):
     _lib.set_option("score_strip", strip)
     try:
         _check(idx, ro, stored, labels, q, k)
+        _lib.set_option("score_filter", 2)       # the same strips through the threshold-filtered selection (137 tiles >= 128)
+        _check(idx, ro, stored, labels, q, k)
     finally:
         _lib.set_option("score_strip", 0)
+        _lib.set_option("score_filter", 1)
 
 
 def test_batched_path_with_exact_duplicates(mods):
