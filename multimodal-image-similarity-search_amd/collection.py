@@ -77,12 +77,19 @@ class FlatCollection:
         suffix = "" if gen == 0 else f".{gen}"
         return os.path.join(self._persist_dir, f"{self.name}.index{suffix}.mmiss")
 
+    def _journal_paths(self, gen: int):
+        base = os.path.join(self._persist_dir, f"{self.name}.journal.{gen}")
+        return base + ".jsonl", base + ".f32"
+
     def persist(self) -> None:
+        """Full snapshot (compaction): metadata file + a new index generation; the journal of the previous generation is
+        dropped. O(N) — called on create, explicitly, and automatically when the journal has grown past a quarter of the
+        collection (see _saved): ordinary add / update / delete only append to the journal."""
         if not self._persist_dir:
             return
         with self._lock:
             old_gen = getattr(self, "_index_gen", 0)
-            new_gen = old_gen + 1 if self._index is not None else old_gen
+            new_gen = old_gen + 1
             blob = {
                 "name": self.name, "metadata": self.metadata, "dim": self._dim, "dtype": self._dtype,
                 "next_label": self._next_label, "ids": self._ids, "labels": self._labels,
@@ -99,11 +106,58 @@ class FlatCollection:
                 self._index.save(self._index_path(new_gen))   # a new file: the previous generation stays intact
             os.replace(tmp, self._meta_path())                 # the atomic switch
             self._index_gen = new_gen
-            if new_gen != old_gen:
+            self._journal_rows = 0
+            for path in (self._index_path(old_gen),) + self._journal_paths(old_gen):
                 try:
-                    os.remove(self._index_path(old_gen))
+                    os.remove(path)
                 except FileNotFoundError:
                     pass
+
+    def _journal(self, record: dict, vectors: Optional[np.ndarray] = None) -> None:
+        """Append one mutation to the journal of the current generation: the vectors (raw float32, as handed to add /
+        update — replay re-normalises them, bit-identically) first, then ONE json line that is the commit record. O(batch),
+        where a full snapshot per uploaded image would be O(N) (10 GB per /api/upload at 10M x 512 f16)."""
+        jl, jv = self._journal_paths(getattr(self, "_index_gen", 0))
+        if vectors is not None:
+            with open(jv, "ab") as f:
+                record["offset"] = f.tell()
+                record["rows"] = int(vectors.shape[0])
+                record["dim"] = int(vectors.shape[1])
+                f.write(np.ascontiguousarray(vectors, dtype=np.float32).tobytes())
+                f.flush()
+                os.fsync(f.fileno())
+        with open(jl, "a") as f:
+            f.write(json.dumps(record) + "\n")
+            f.flush()
+            os.fsync(f.fileno())
+        self._journal_rows = getattr(self, "_journal_rows", 0) + max(1, len(record.get("ids", [])))
+
+    def _replay_journal(self) -> None:
+        jl, jv = self._journal_paths(self._index_gen)
+        if not os.path.exists(jl):
+            return
+        vec = np.memmap(jv, dtype=np.float32, mode="r") if os.path.exists(jv) and os.path.getsize(jv) else None
+        autosave, self._autosave = self._autosave, False   # replay must not journal again
+        try:
+            with open(jl) as f:
+                for line in f:
+                    try:
+                        rec = json.loads(line)
+                    except ValueError:
+                        break                                # a torn last line: the mutation was never committed
+                    emb = None
+                    if "offset" in rec:
+                        o, n, d = rec["offset"] // 4, rec["rows"], rec["dim"]
+                        emb = np.array(vec[o:o + n * d]).reshape(n, d)
+                    if rec["op"] == "add":
+                        self.add(rec["ids"], emb, rec.get("metadatas"), rec.get("documents"))
+                    elif rec["op"] == "update":
+                        self.update(rec["ids"], emb, rec.get("metadatas"), rec.get("documents"), _replace_metadata=True)
+                    elif rec["op"] == "delete":
+                        self.delete(rec["ids"])
+                    self._journal_rows = getattr(self, "_journal_rows", 0) + max(1, len(rec.get("ids", [])))
+        finally:
+            self._autosave = autosave
 
     def _load(self) -> None:
         with open(self._meta_path()) as f:
@@ -123,9 +177,19 @@ class FlatCollection:
             self._index.load(self._index_path(self._index_gen))
             if self._index.count() != len(self._labels):
                 raise RuntimeError("collection files are inconsistent (row count differs from id count)")
+        self._journal_rows = 0
+        self._replay_journal()
 
-    def _saved(self):
-        if self._autosave:
+    def _saved(self, record: Optional[dict] = None, vectors: Optional[np.ndarray] = None):
+        """After a mutation (called under the lock): append it to the journal; compact into a full snapshot once the
+        journal holds more than max(4096, a quarter of the collection) rows."""
+        if not (self._autosave and self._persist_dir):
+            return
+        if record is None:
+            self.persist()
+            return
+        self._journal(record, vectors)
+        if self._journal_rows > max(4096, len(self._ids) // 4):
             self.persist()
 
     # ------------------------------------------------------------------ helpers
@@ -175,7 +239,7 @@ class FlatCollection:
             for lab, m, d in zip(labels.tolist(), metadatas, documents):
                 self._meta[lab] = dict(m) if m is not None else None
                 self._docs[lab] = d
-            self._saved()
+            self._saved({"op": "add", "ids": ids, "metadatas": metadatas, "documents": documents}, emb)
 
     def query(self, query_embeddings=None, n_results: int = 10, include: Sequence[str] = ("metadatas", "documents", "distances"),
               **_unused) -> dict:
@@ -239,7 +303,7 @@ class FlatCollection:
                 out["embeddings"] = self._index.get(labs) if (self._index is not None and labs.size) else np.zeros((0, self._dim or 0), np.float32)
             return out
 
-    def update(self, ids, embeddings=None, metadatas=None, documents=None) -> None:
+    def update(self, ids, embeddings=None, metadatas=None, documents=None, _replace_metadata: bool = False) -> None:
         ids = _as_list(ids)
         with self._lock:
             missing = [i for i in ids if i not in self._by_id]
@@ -249,15 +313,20 @@ class FlatCollection:
             if metadatas is not None:
                 for lab, m in zip(labs, _as_list(metadatas)):
                     if m is not None:
-                        merged = dict(self._meta.get(lab) or {})
+                        merged = {} if _replace_metadata else dict(self._meta.get(lab) or {})
                         merged.update(m)  # chroma merges keys on update
                         self._meta[lab] = merged
             if documents is not None:
                 for lab, d in zip(labs, _as_list(documents)):
                     self._docs[lab] = d
+            emb = None
             if embeddings is not None:
-                self._index.update(np.asarray(labs, dtype=np.int64), self._embeddings_array(embeddings))
-            self._saved()
+                emb = self._embeddings_array(embeddings)
+                self._index.update(np.asarray(labs, dtype=np.int64), emb)
+            # the journal records the RESULTING metadata (replay replaces instead of merging: idempotent)
+            self._saved({"op": "update", "ids": ids,
+                         "metadatas": [self._meta.get(l) for l in labs] if metadatas is not None else None,
+                         "documents": [self._docs.get(l) for l in labs] if documents is not None else None}, emb)
 
     def delete(self, ids=None) -> None:
         with self._lock:
@@ -276,7 +345,7 @@ class FlatCollection:
                 del self._by_id[i]
                 self._meta.pop(l, None)
                 self._docs.pop(l, None)
-            self._saved()
+            self._saved({"op": "delete", "ids": ids})
 
     def peek(self, limit: int = 10) -> dict:
         return self.get(limit=limit)
@@ -320,5 +389,5 @@ class PersistentClient:
         self._open.pop(name, None)
         for fn in os.listdir(self.path):   # the metadata file and every index generation of this collection
             if fn == name + ".meta.json" or fn == name + ".meta.json.tmp" or (
-                    fn.startswith(name + ".index") and fn.endswith(".mmiss")):
+                    fn.startswith(name + ".index") and fn.endswith(".mmiss")) or fn.startswith(name + ".journal."):
                 os.remove(os.path.join(self.path, fn))

@@ -17,6 +17,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import utils
+from .collection import DuplicateIDError
 from .index import blend
 
 logger = logging.getLogger("image-match")
@@ -135,7 +136,13 @@ def process_image(image, image_id: str, metadata: Optional[Dict[str, Any]] = Non
     embedding = embedding_result["image"][0].tolist()
     metadata = dict(metadata or {})
     metadata.setdefault("id", image_id)
-    col.add(ids=[image_id], embeddings=[embedding], metadatas=[metadata], documents=[document])
+    try:
+        col.add(ids=[image_id], embeddings=[embedding], metadatas=[metadata], documents=[document])
+    except DuplicateIDError:
+        # a concurrent upload of the same image won the race between the check above and this add: same answer as the
+        # check would have given (the caller's 409), not a 500
+        existing = col.get(ids=[image_id], include=["metadatas"])
+        return (existing["metadatas"][0] if existing["ids"] else metadata), False
     return metadata, True
 
 

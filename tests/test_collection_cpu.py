@@ -76,3 +76,44 @@ def test_persistent_client_reopens_collection(colmod, tmp_path):
         again.create_collection("image-match")
     with pytest.raises(ValueError):
         again.get_collection("other")
+
+
+def test_mutations_are_journaled_not_resnapshotted(colmod, tmp_path):
+    """An upload must cost O(1) on disk, not a rewrite of the whole index (chromadb persists incrementally too): add / update
+    / delete append to the journal of the current generation; reopening replays it; a torn last line is an uncommitted
+    mutation; the journal is compacted into a new snapshot once it outgrows a quarter of the collection."""
+    import os
+
+    client = colmod.PersistentClient(path=str(tmp_path))
+    col = client.create_collection("image-match", metadata={"hnsw:space": "cosine"})
+    gen0 = col._index_gen
+    v = _vecs(40, seed=3)
+    for i in range(40):
+        col.add(ids=[f"img_{i}"], embeddings=[v[i].tolist()], metadatas=[{"n": i}], documents=[f"c{i}"])
+    col.update(ids=["img_5"], metadatas=[{"filter_results_json": "{}"}])
+    col.update(ids=["img_6"], embeddings=_vecs(1, seed=77))
+    col.delete(ids=["img_7", "img_8"])
+    assert col._index_gen == gen0                                   # no new snapshot: 43 journal records
+    files = sorted(os.listdir(tmp_path))
+    assert f"image-match.journal.{gen0}.jsonl" in files and f"image-match.journal.{gen0}.f32" in files
+    assert sum(1 for _ in open(tmp_path / f"image-match.journal.{gen0}.jsonl")) == 43
+    assert os.path.getsize(tmp_path / f"image-match.journal.{gen0}.f32") == 41 * 128 * 4
+    again = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert again.count() == 38 and again.get(ids=["img_5"])["metadatas"][0] == {"n": 5, "filter_results_json": "{}"}
+    q = _vecs(3, seed=9)
+    r1, r2 = col.query(query_embeddings=q, n_results=10), again.query(query_embeddings=q, n_results=10)
+    assert r1["ids"] == r2["ids"] and r1["distances"] == r2["distances"] and r1["metadatas"] == r2["metadatas"]
+    assert again.query(query_embeddings=_vecs(1, seed=77), n_results=1)["ids"] == [["img_6"]]
+    # a crash in the middle of the next append: the half-written line is ignored
+    with open(tmp_path / f"image-match.journal.{gen0}.jsonl", "a") as f:
+        f.write('{"op": "add", "ids": ["img_x"], "meta')
+    third = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert third.count() == 38 and "img_x" not in third.get(include=[])["ids"]
+    # compaction: past max(4096, n/4) journaled rows the collection snapshots itself and starts a fresh journal
+    big = _vecs(4200, seed=5)
+    third.add(ids=[f"b{i}" for i in range(4200)], embeddings=big)
+    assert third._index_gen == gen0 + 1 and third._journal_rows == 0
+    assert not os.path.exists(tmp_path / f"image-match.journal.{gen0}.jsonl")
+    fourth = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert fourth.count() == 38 + 4200
+    assert fourth.query(query_embeddings=big[17:18], n_results=1)["ids"] == [["b17"]]

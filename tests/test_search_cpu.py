@@ -85,3 +85,28 @@ def test_errors_become_empty_lists_like_the_reference(env):
     utils.set_clip_model(None, None)
     assert search.search_by_text("x") == []  # no weights configured -> load_clip_model raises -> []
     assert search.search_multimodal(_img(0), "x") == []
+
+
+def test_concurrent_upload_of_the_same_image_is_a_duplicate_not_an_error(env):
+    """process_image checks, embeds, then adds (main.py:631-640,685-687,735-740). Two uploads of the same image racing
+    through that window: the loser's add raises DuplicateIDError — it must come back as (existing metadata, False), the
+    route's 409, not as an exception (500)."""
+    search, utils, col, enc = env
+    real_get = col.get
+    calls = {"n": 0}
+
+    def racing_get(ids=None, include=("metadatas", "documents"), **kw):
+        calls["n"] += 1
+        if calls["n"] == 1:   # the duplicate check of the losing upload: nothing there yet ...
+            out = real_get(ids=ids, include=include, **kw)
+            # ... and the winning upload lands between the check and the add
+            col.add(ids=["img_same"], embeddings=[enc.encode_image_rgb([_img(5)])[0].tolist()], metadatas=[{"id": "img_same", "who": "winner"}])
+            return out
+        return real_get(ids=ids, include=include, **kw)
+
+    col.get = racing_get
+    try:
+        meta, stored = search.process_image(_img(5), "img_same", {"who": "loser"})
+    finally:
+        col.get = real_get
+    assert stored is False and meta["who"] == "winner" and col.count() == 1
