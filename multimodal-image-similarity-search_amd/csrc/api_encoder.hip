@@ -131,9 +131,14 @@ struct mmiss_encoder {
 
 namespace {
 
+// hipMemset of device memory is enqueued on the NULL stream and may return before it has run; the handle's own stream is
+// non-blocking, i.e. NOT ordered behind the null stream — a kernel of the next call (a weight upload, the first encode)
+// could otherwise write the buffer BEFORE the late memset clears it. Seen once as a finite but wrong embedding of the
+// first handle created in a busy process. So: wait for the clear before handing the buffer out (allocation time only).
 int alloc_zero(DevBuf& b, size_t bytes) {
     MM_TRY(b.alloc(bytes));
-    MM_HIP(hipMemset(b.p, 0, bytes));
+    MM_HIP(hipMemsetAsync(b.p, 0, bytes, nullptr));
+    MM_HIP(hipStreamSynchronize(nullptr));
     return MMISS_OK;
 }
 
