@@ -707,8 +707,17 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         MM_TRY(launch_rerank(ix, st, r, Q));
     }
     ix->stat_queries += Q;
+    auto copy_out = [&]() -> int {  // results to the caller's host buffers
+        MM_HIP(hipMemcpyAsync(out_labels, d_lab, (size_t)Q * k * 8, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)Q * k * 4, hipMemcpyDeviceToHost, st));
+        if (out_count) MM_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+        return MMISS_OK;
+    };
+    bool copied = false;
     if (guard) {
-        // one 4-byte read-back per call: how many queries could not be proven exact (almost always 0)
+        // one 4-byte read-back per call: how many queries could not be proven exact (almost always 0). With host outputs the
+        // results ride in front of it, so the call still has ONE stream synchronisation.
+        if (!out_dev) { MM_TRY(copy_out()); copied = true; }
         int nflag = 0;
         MM_TRY(read_nflag(ix, st, &nflag));
         if (nflag > 0) {
@@ -718,14 +727,15 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
                 if (fl[q]) which.push_back(q);
             ix->stat_flagged += (int64_t)which.size();
             MM_TRY(widen_queries(ix, st, which, k, d_lab, d_dist, d_cnt));
+            copied = false;  // the widened rows replace what was copied
         }
     }
     if (!out_dev) {
-        MM_HIP(hipMemcpyAsync(out_labels, d_lab, (size_t)Q * k * 8, hipMemcpyDeviceToHost, st));
-        MM_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)Q * k * 4, hipMemcpyDeviceToHost, st));
-        if (out_count) MM_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
-        MM_HIP(hipStreamSynchronize(st));
-    } else if (!ix->has_user_stream) {
+        if (!copied) {
+            MM_TRY(copy_out());
+            MM_HIP(hipStreamSynchronize(st));
+        }
+    } else if (!ix->has_user_stream && !guard) {
         MM_HIP(hipStreamSynchronize(st));
     }
     return MMISS_OK;
