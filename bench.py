@@ -528,6 +528,26 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
     res["headline_mvec_per_s"] = res["Q1"]["mvec_per_s"]
     res["exactness"] = idx.guard_stats()
     idx.close()
+    # BASELINE configs[4] index shape: one of the 8 row shards of the 50M x 768 f16 index (6.25M rows, 9.6 GB), N = 1 only
+    if world == 1 and N >= 10_000_000:
+        N8, D8 = 6_250_000, 768
+        idx8 = FlatIndex(D8, "f16", device=local_rank, capacity=N8)
+        for r0 in range(0, N8, 1_250_000):
+            idx8.add(torch.randn(1_250_000, D8, device=dev, generator=gen), np.arange(r0, r0 + 1_250_000, dtype=np.int64))
+        shard = {"rows": N8, "dim": D8, "dtype": "f16", "note": "one GPU's shard of BASELINE configs[4] (50M x 768 over 8 GPUs)"}
+        for Q, iters in ((1, 10), (128, 5)):
+            q = torch.randn(Q, D8, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+            idx8.query(q, K_TOP)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                idx8.query(q, K_TOP)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / iters
+            shard[f"Q{Q}"] = {"ms_per_batch": round(dt * 1e3, 3), "mvec_per_s": round(N8 / dt / 1e6, 1),
+                              "hbm_gbs_equiv": round(N8 * D8 * 2 / dt / 1e9, 1)}
+        idx8.close()
+        res["shard_50Mx768"] = shard
     return res
 
 

@@ -245,3 +245,29 @@ def test_small_calls_fall_back_to_bf16_kernels(env):
     with pytest.raises(KeyError):
         late.set_precision("int4")
     late.close()
+
+
+def test_longclip_l14_full_depth_vision_bf16_and_fp8(env):
+    """BASELINE configs[4] geometry at FULL depth: the reference model's vision tower (ViT-L/14: 24 layers, d = 1024,
+    16 heads, T = 257, proj 768; backend/app/utils.py:16-17), seeded weights, 8 images = 2056 token rows (fp8 kernels
+    active), against the fp32 oracle: bf16 within the north_star tolerance, fp8 within its own measured bar."""
+    import dataclasses
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.LONGCLIP_L14, t_layers=1, t_vocab=1000, eos_token_id=999)  # text tower cut: vision only here
+    W = co.init_weights(s, seed=51)
+    rng = np.random.Generator(np.random.Philox(52))
+    px = rng.standard_normal((8, 3, 224, 224), dtype=np.float32)
+    ref = co.embed_images(px, W, s)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=8, max_batch_text=2)
+    enc.load_state_dict(W)
+    d16 = 1 - _cos(enc.encode_image(px), ref)
+    enc.set_precision("fp8")
+    (out8, kern) = _with_kernels(lambda: enc.encode_image(px))
+    d8 = 1 - _cos(out8, ref)
+    enc.close()
+    print("L/14 24 layers: 1-cos bf16", float(d16.max()), "fp8", float(d8.max()))
+    assert kern.get("gemm_fp8_bias", 0) == 24 and kern.get("gemm_fp8_bias_resid", 0) == 23, kern
+    assert d16.max() < COS_TOL, d16
+    assert d8.max() < COS_TOL_FP8, d8
