@@ -360,3 +360,23 @@ def test_full_size_properties_1m_rows():
         np.testing.assert_array_equal(d1.cpu().numpy()[0].view(np.uint32), dist[j].view(np.uint32))
     l16, d16, _ = idx.query(q[:16], 10)                    # Q = 16 -> scan path with a full MFMA tile of queries
     np.testing.assert_array_equal(l16.cpu().numpy(), lab[:16])
+
+
+@pytest.mark.parametrize("S,k,Q", [(8, 1000, 3), (20, 1000, 2), (5, 2040, 2), (64, 10, 33)])
+def test_merge_topk_any_shard_count(mods, S, k, Q):
+    """The UI's "All" = 1000 hits (main.py:757) on 8 shards is 8000 entries per query (one LDS pass); 20 shards x 1000 and
+    5 x 2040 go through several merge levels. Against the oracle's merge, incl. empty slots and ties across shards."""
+    _, _, merge_topk, ro = mods
+    rng = np.random.Generator(np.random.Philox(S * k + Q))
+    dist = np.sort(rng.random((S, Q, k), dtype=np.float32), axis=2)
+    labels = np.empty((S, Q, k), dtype=np.int64)
+    for s_ in range(S):   # disjoint label ranges per shard, ascending within a list like a real per-shard result
+        labels[s_] = np.sort(rng.choice(10 * k, size=(Q, k), replace=True), axis=1) + s_ * 10 * k
+    dist[1, 0, :5] = dist[0, 0, :5]                      # exact ties across shards: the smaller label wins
+    labels[S - 1, :, k - 7:] = -1                         # a shard with fewer than k rows
+    dist[S - 1, :, k - 7:] = np.inf
+    ml, md, mc = merge_topk(dist, labels)
+    ol, od, oc = ro.merge_shards(dist, labels, k)
+    np.testing.assert_array_equal(ml, ol)
+    np.testing.assert_array_equal(md.view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(mc, oc)
