@@ -96,6 +96,7 @@ SIGNATURES = {
     "mmiss_dbg_encoder_record_taps": (_I, [_P, _I]),
     "mmiss_dbg_encoder_set_fuse_ln": (_I, [_P, _I]),
     "mmiss_dbg_set_option": (_I, [C.c_char_p, _I]),
+    "mmiss_dbg_build_flags": (_I, []),
     "mmiss_dbg_quantize_weights_fp8": (_I, [_I, _P, _P, _P, _P, _I32, _I32]),
     "mmiss_dbg_layernorm_mxfp8": (_I, [_I, _P, _P, _P, _P, _P, _P, _I32, _I32, C.c_float]),
     "mmiss_dbg_gemm8": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32]),
@@ -168,6 +169,11 @@ def current_stream_ptr(device=None):
     import torch
 
     return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def has_experiments() -> bool:
+    """True when libmmiss.so was built with `make EXPERIMENTS=1` (measured-slower GEMM / LayerNorm alternatives)."""
+    return bool(load().mmiss_dbg_build_flags() & 1)
 
 
 def set_option(key: str, value: int) -> None:

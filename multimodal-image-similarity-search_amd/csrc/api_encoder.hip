@@ -3,7 +3,9 @@
 #include "common.h"
 #include "gemm_bf16.h"
 #include "gemm_bf16_256.h"
-#include "gemm_bf16_ring.h"
+#ifdef MMISS_EXPERIMENTS
+#include "gemm_bf16_ring.h"  // measured-slower alternatives, kept for A/B in debug builds (make EXPERIMENTS=1)
+#endif
 #include "gemm_fp8.h"
 #include "encoder_kernels.h"
 #include "preprocess_kernels.h"
@@ -283,10 +285,12 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_BF16, bm_qkv, tw.xb.p, L.wqkv_f.p, ep, padded(bm_qkv), 3 * d, d));
+#ifdef MMISS_EXPERIMENTS
         } else if (fuse) {
             ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln1g.as<float>(); ep.ln_b = L.ln1b.as<float>();
             ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.x.as<float>(), L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
+#endif
         } else if (fp8) {
             MM_TRY(launch_layernorm_mxfp8(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h8.as<uint8_t>(),
                                           tw.hs.as<uint8_t>(), M, d, eps));
@@ -335,10 +339,12 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, bm_mlp, tw.xb.p, L.w1_f.p, ep, padded(bm_mlp), tw.mlp, d));
+#ifdef MMISS_EXPERIMENTS
         } else if (fuse) {
             ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln2g.as<float>(); ep.ln_b = L.ln2b.as<float>();
             ep.ln_parts = parts; ep.ln_eps = eps;
             MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.x.as<float>(), L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
+#endif
         } else if (fp8) {
             // LN2 -> MXFP8, FC1 + QuickGELU -> MXFP8 (per row and 64 columns), FC2 + residual: `u` crosses HBM as 1 byte
             MM_TRY(launch_layernorm_mxfp8(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h8.as<uint8_t>(),
@@ -944,8 +950,19 @@ extern "C" int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t
 extern "C" int mmiss_dbg_encoder_set_fuse_ln(mmiss_encoder* enc, int on) {
     if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
     std::lock_guard<std::mutex> lk(enc->mu);
+#ifndef MMISS_EXPERIMENTS
+    if (on == 1) MM_FAIL(MMISS_ERR_UNSUPPORTED, "LayerNorm mode 1 (normalise while staging) exists only in builds with MMISS_EXPERIMENTS");
+#endif
     enc->ln_mode = on < 0 ? -1 : (on > 2 ? 2 : on);  // -1 automatic, 0 separate kernels, 1 operand-fused, 2 folded
     return MMISS_OK;
+}
+
+extern "C" int mmiss_dbg_build_flags(void) {
+#ifdef MMISS_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int mmiss_dbg_encoder_record_taps(mmiss_encoder* enc, int on) {
@@ -1007,7 +1024,11 @@ extern "C" int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant
         ep.splitk_ws = dbg_splitk.as<float>(); ep.splitk_ws_bytes = dbg_splitk.bytes;
     }
     if (variant == 256) return launch_gemm256(reinterpret_cast<hipStream_t>(hip_stream), epi, A, W, ep, M, N, K);
+#ifdef MMISS_EXPERIMENTS
     if (variant > 1000 && variant < 2000) return launch_gemm_ring(reinterpret_cast<hipStream_t>(hip_stream), epi, variant - 1000, A, W, ep, M, N, K);
+#else
+    if (variant > 1000) MM_FAIL(MMISS_ERR_UNSUPPORTED, "GEMM variant %d exists only in builds with MMISS_EXPERIMENTS (make EXPERIMENTS=1)", variant);
+#endif
     return launch_gemm(reinterpret_cast<hipStream_t>(hip_stream), epi, variant, A, W, ep, M, N, K);
 }
 
@@ -1023,7 +1044,11 @@ extern "C" int mmiss_dbg_gemm_time(int device, int epi, int variant, const void*
     MM_HIP(hipEventCreate(&e1));
     auto run = [&]() -> int {
         if (variant == 256) return launch_gemm256(nullptr, epi, A, W, ep, M, N, K);
+#ifdef MMISS_EXPERIMENTS
         if (variant > 1000 && variant < 2000) return launch_gemm_ring(nullptr, epi, variant - 1000, A, W, ep, M, N, K);
+#else
+        if (variant > 1000) MM_FAIL(MMISS_ERR_UNSUPPORTED, "GEMM variant %d exists only in builds with MMISS_EXPERIMENTS", variant);
+#endif
         return launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K);
     };
     for (int i = 0; i < 3; ++i) MM_TRY(run());

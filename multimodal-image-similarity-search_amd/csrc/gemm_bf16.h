@@ -562,6 +562,9 @@ static inline int gemm_pick_bm(int64_t M_rows, int N) {
 // the previous kernel has left it completely), so they are OFF by default (option gemm_wide = 1 turns the cost model on).
 static inline int gemm_pick_variant(int64_t M_rows, int N) {
     int best = gemm_pick_bm(M_rows, N);
+#ifndef MMISS_EXPERIMENTS
+    return best;
+#endif
     if ((N % 256) != 0 || mmiss_option("gemm_wide", 0) == 0) return best;
     const double effn[3] = {1.00, 0.93, 0.89}, effw[3] = {0.97, 0.86, 0.84};
     const int bms[3] = {128, 160, 192};
@@ -630,6 +633,7 @@ static int launch_gemm_fold(hipStream_t st, int epi, int bm, const void* A, cons
     MM_FAIL(MMISS_ERR_ARG, "gemm_fold: unsupported tile height %d", bm);
 }
 
+#ifdef MMISS_EXPERIMENTS  // ln_mode 1: measured slower (342-371 TF), kept for A/B in debug builds
 // LayerNorm-fused bf16 GEMM: X f32 [M,K] (the residual stream), ep.ln_* set; epilogues BIAS_BF16 / BIAS_QGELU_BF16.
 static int launch_gemm_ln(hipStream_t st, int epi, int bm, const float* X, const void* W, const GemmEpi& ep, int M, int N,
                           int K) {
@@ -653,6 +657,8 @@ static int launch_gemm_ln(hipStream_t st, int epi, int bm, const float* X, const
 #undef GEMM_LN_CASE
     MM_FAIL(MMISS_ERR_ARG, "gemm_ln: unsupported tile height %d", bm);
 }
+
+#endif  // MMISS_EXPERIMENTS
 
 // Two or three staging buffers: a grid of at most 256 workgroups puts one workgroup on a CU whatever its LDS footprint,
 // so the deeper pipeline costs no occupancy there and hides the load latency the second workgroup would have hidden.
@@ -680,10 +686,12 @@ static int launch_gemm_bm(hipStream_t st, int bm, const void* A, const void* W, 
         case 128: return launch_gemm_stages<IN, 128, EPI>(st, A, W, ep, M, N, K);
         case 160: return launch_gemm_stages<IN, 160, EPI>(st, A, W, ep, M, N, K);
         case 192: return launch_gemm_stages<IN, 192, EPI>(st, A, W, ep, M, N, K);
-        // 2000 + BM: the BM x 256 tile with 8 waves (one workgroup per CU)
+#ifdef MMISS_EXPERIMENTS
+        // 2000 + BM: the BM x 256 tile with 8 waves (one workgroup per CU): slower inside the encode, debug builds only
         case 2128: return launch_gemm_inst<IN, 128, EPI, false, 4>(st, A, W, ep, M, N, K);
         case 2160: return launch_gemm_inst<IN, 160, EPI, false, 4>(st, A, W, ep, M, N, K);
         case 2192: return launch_gemm_inst<IN, 192, EPI, false, 4>(st, A, W, ep, M, N, K);
+#endif
     }
     MM_FAIL(MMISS_ERR_ARG, "gemm: unsupported tile height %d", bm);
 }

@@ -72,7 +72,9 @@ def test_last_layer_pruning_matches_full_computation(tiny):
     ids = co.synthetic_text_ids(7, s.t_ctx, s.t_vocab, s.eos_token_id, seed=78)
     np.testing.assert_allclose(pruned.encode_image(px), enc.encode_image(px), atol=1e-6)
     np.testing.assert_allclose(pruned.encode_text(ids), enc.encode_text(ids), atol=1e-6)
-    for mode in (1, 2):  # the pruned tail is the same whatever the LayerNorm mode of the other layers
+    from mmiss_amd import _lib
+
+    for mode in ((1, 2) if _lib.has_experiments() else (2,)):  # the pruned tail is the same whatever the LayerNorm mode
         pruned.set_fuse_ln(mode)
         assert (1 - _cos(pruned.encode_image(px), co.embed_images(px, W, s))).max() < COS_TOL
     assert (1 - _cos(pruned.encode_text(ids), co.embed_texts(ids, W, s))).max() < COS_TOL
@@ -89,8 +91,10 @@ def test_layernorm_modes_agree(tiny):
     px = rng.standard_normal((6, 3, s.v_image, s.v_image), dtype=np.float32) * 3 + 1.5  # non-zero row means
     ids = co.synthetic_text_ids(6, s.t_ctx, s.t_vocab, s.eos_token_id, seed=92)
     ref_i, ref_t = co.embed_images(px, W, s), co.embed_texts(ids, W, s)
+    from mmiss_amd import _lib
+
     outs = []
-    for mode in (0, 1, 2):
+    for mode in ((0, 1, 2) if _lib.has_experiments() else (0, 2)):  # mode 1 (slower) only in EXPERIMENTS builds
         e = ClipEncoder(ClipShape.from_any(s), max_batch_image=8, max_batch_text=8)
         e.load_state_dict(W)
         e.set_fuse_ln(mode)

@@ -113,6 +113,8 @@ def test_gemm_ring_pipeline(env, bm, M, N, K):
     """The 4-slot ring variant (32-deep stages, counted vmcnt): stage counts 1..96 cover prologue, steady state and
     tail; results must be bit-identical to the drain-per-tile kernel (same per-element k order)."""
     torch, _lib, lib = env
+    if not _lib.has_experiments():
+        pytest.skip("measured-slower variant: only in `make EXPERIMENTS=1` builds")
     g = torch.Generator(device="cuda").manual_seed(bm + M + N + K)
     A = _bf16(torch.randn(M, K, device="cuda", generator=g))
     W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
@@ -147,6 +149,8 @@ def test_gemm_wide_tile(env, bm, M, N, K):
     """The BM x 256 tile with 8 waves (variant 2000 + BM): same arithmetic order per element as the BM x 128 tile, so
     bit-identical to it, and all epilogues against the fp32 restatement."""
     torch, _lib, lib = env
+    if not _lib.has_experiments():
+        pytest.skip("measured-slower variant: only in `make EXPERIMENTS=1` builds")
     g = torch.Generator(device="cuda").manual_seed(bm + M + N + K)
     A = _bf16(torch.randn(M, K, device="cuda", generator=g))
     W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
