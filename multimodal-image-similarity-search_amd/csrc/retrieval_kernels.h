@@ -596,47 +596,24 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
     for (int i = tid; i < npow; i += nthreads) { sd[i] = INFINITY; sr[i] = INT32_MAX; }
     __syncthreads();
-    // A wave re-scores RB candidates per trip: their row gathers (random 1-2 KB rows, the latency of this kernel) are all
-    // issued before the first butterfly. Each candidate keeps its own accumulator and its own fixed summation order, so the
-    // distances are bit-identical to the one-at-a-time form.
-    constexpr int RB = 4;
-    for (int c0 = wave * RB; c0 < a.ncand; c0 += nwaves * RB) {
-        int64_t row[RB];
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int c = c0 + u;
-            row[u] = -1;
-            if (c < a.ncand) {
-                if (a.group_mode) {
-                    const int g = a.cand[(size_t)b * a.cand_stride + (c >> 4)];
-                    if (g >= 0) {
-                        const int64_t r = groupmax_row(g, c & 15);
-                        if (r < a.nrows) row[u] = r;
-                    }
-                } else {
-                    row[u] = a.cand[(size_t)b * a.cand_stride + c];
-                }
-            }
+    for (int c = wave; c < a.ncand; c += nwaves) {
+        int64_t row;
+        if (a.group_mode) {
+            const int g = a.cand[(size_t)b * a.cand_stride + (c >> 4)];
+            if (g < 0) continue;  // wave-uniform
+            row = groupmax_row(g, c & 15);
+            if (row >= a.nrows) continue;
+        } else {
+            row = a.cand[(size_t)b * a.cand_stride + c];
+            if (row < 0) continue;  // wave-uniform
         }
-        double acc[RB];
-#pragma unroll
-        for (int u = 0; u < RB; ++u) acc[u] = 0.0;
-        for (int d = lane; d < a.D; d += 64) {
-            const double qd = (double)qv[d];
-            T rvv[RB];
-#pragma unroll
-            for (int u = 0; u < RB; ++u)   // (wave-uniform predicate: absent candidates load nothing — the index may be empty)
-                rvv[u] = row[u] < 0 ? (T)0.0f : reinterpret_cast<const T*>(a.rows)[(size_t)row[u] * a.D + d];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) acc[u] = acc[u] + qd * widen<T>(rvv[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const double dot = wave_butterfly_sum(acc[u]);
-            if (lane == 0 && row[u] >= 0) {
-                sd[c0 + u] = (float)(1.0 - dot);
-                sr[c0 + u] = (int32_t)row[u];
-            }
+        const T* rv = reinterpret_cast<const T*>(a.rows) + (size_t)row * a.D;
+        double acc = 0.0;
+        for (int d = lane; d < a.D; d += 64) acc = acc + (double)qv[d] * widen<T>(rv[d]);
+        const double dot = wave_butterfly_sum(acc);
+        if (lane == 0) {
+            sd[c] = (float)(1.0 - dot);
+            sr[c] = (int32_t)row;
         }
     }
     __syncthreads();
