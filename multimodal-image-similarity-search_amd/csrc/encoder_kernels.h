@@ -258,6 +258,19 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
     const uint16_t* base = qkv + (size_t)b * T * ld + h * 64;
 
     constexpr int NW = ATT_THREADS(NKP) / 64;
+    const int fr = lane & 15, fg = lane >> 4;
+    // The Q fragments of this wave's first query tile are fetched BEFORE the K/V image is staged: their global latency then
+    // overlaps the staging loads instead of following the barrier (the kernel is a chain of dependent latencies, not
+    // bandwidth: 3072 workgroups of ~20 KB each at T = 50).
+    const int qt_first = wave + NW * blockIdx.y;
+    bf16x8 qf_first[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 raw = {0u, 0u, 0u, 0u};
+        const int q = qt_first * 16 + fr;
+        if (q < T) raw = *reinterpret_cast<const u32x4*>(base + (size_t)q * ld + s * 32 + fg * 8);
+        qf_first[s] = __builtin_bit_cast(bf16x8, raw);
+    }
     for (int idx = tid; idx < TP * 8; idx += NW * 64) {
         const int row = idx >> 3, c = idx & 7;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
@@ -270,17 +283,21 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
     }
     __syncthreads();
 
-    const int fr = lane & 15, fg = lane >> 4;
     const int nqt = (T + 15) >> 4;
     // gridDim.y workgroups share one (b, h): small batches split the query tiles so that the grid still fills the chip
-    for (int qt = wave + NW * blockIdx.y; qt < nqt; qt += NW * gridDim.y) {
+    for (int qt = qt_first; qt < nqt; qt += NW * gridDim.y) {
         const int q = qt * 16 + fr;
         bf16x8 qf[2];
+        if (qt == qt_first) {
+            qf[0] = qf_first[0];
+            qf[1] = qf_first[1];
+        } else {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 raw = {0u, 0u, 0u, 0u};
-            if (q < T) raw = *reinterpret_cast<const u32x4*>(base + (size_t)q * ld + s * 32 + fg * 8);
-            qf[s] = __builtin_bit_cast(bf16x8, raw);
+            for (int s = 0; s < 2; ++s) {
+                u32x4 raw = {0u, 0u, 0u, 0u};
+                if (q < T) raw = *reinterpret_cast<const u32x4*>(base + (size_t)q * ld + s * 32 + fg * 8);
+                qf[s] = __builtin_bit_cast(bf16x8, raw);
+            }
         }
         if constexpr (NKP > 4) {
             // ---- long sequences (ViT-L/14: 257 keys, LongCLIP text: 248): holding all 2*NKP score tiles costs 288 VGPRs
