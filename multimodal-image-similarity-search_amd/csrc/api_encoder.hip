@@ -250,9 +250,10 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     if (const int f = mmiss_option("gemm_bm_mlp", 0)) bm_mlp = f;
     auto padded = [&](int bm) { return (int)round_up(M, bm % 1000); };
     const int bm8_qkv = gemm_pick_bm(M, 3 * d), bm8_d = gemm_pick_bm(M, d), bm8_mlp = gemm_pick_bm(M, tw.mlp);
-    // 256 x 256 phase-pipelined tile for the widest GEMMs: from N = 4096 (the ViT-L/14 FC1: 336 -> 320 us inside the bs-128
-    // encode, +2 % images/s; the L/14 QKV at N = 3072 and the B/32 GEMMs do not gain). Option gemm_256 = minimum N, 0 = never.
-    const int min_n256 = mmiss_option("gemm_256", 4096);
+    // 256 x 256 phase-pipelined tile for the widest GEMMs. Round 1 used it from N = 4096 (the ViT-L/14 FC1: 336 -> 320 us);
+    // with the banded tile order the 128-column kernel now does that GEMM in 292 us (312 us on the 256 x 256 tile, whose
+    // 2064 tiles are 8.06 rounds of 256 CUs), so it is off by default. Option gemm_256 = minimum N, 0 = never.
+    const int min_n256 = mmiss_option("gemm_256", 0);
     auto use256 = [&](int N) { return plain && min_n256 > 0 && N >= min_n256 && (N % 256) == 0 && (d % 64) == 0 && M > 512; };
     // split-K scratch for the narrow long-K GEMM (FC2) while its grid is far below the CU count
     if (gemm_splitk_candidate((int64_t)((M + 127) / 128) * (d / GEMM_BN), tw.mlp))

@@ -593,11 +593,13 @@ static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const 
     if (N % BN) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm: N=%d is not a multiple of the %d-column tile", N, BN);
     const int nwg = (M / BM) * (N / BN);
     GemmEpi e2 = ep;
-    // Tile order of the wide GEMMs (QKV, FC1: >= 16 column tiles): bands of 5 m-tiles, m fastest inside a band. The ~64
+    // Tile order of the wide GEMMs (>= 8 column tiles): bands of 5 m-tiles, m fastest inside a band. The ~64
     // tiles an XCD runs at once then touch 5 A panels + ~13 W panels (~4 MB, the L2's size) instead of ~3 + all W panels:
     // FETCH_SIZE of the folded FC1 189 -> 136 MB per launch (QKV 117 -> 107 MB) at unchanged time (profiles/r02_traffic.json;
-    // 10-tile bands: 150 MB). The narrow GEMMs (N = hidden: 6-8 column tiles) keep n fastest.
-    if (e2.m_fast == 0 && N / BN >= 16) e2.m_fast = mmiss_option("gemm_band", 5);
+    // 10-tile bands: 150 MB). The narrowest GEMMs (fewer than 8 column tiles) keep n fastest.
+    // (ViT-L/14, 32896 rows: also the N = 1024 GEMMs gain — FC2 322 -> 310 us, out-proj 113 -> 109 us; ViT-B/32's N = 768
+    // GEMMs, 6 column tiles, do not)
+    if (e2.m_fast == 0 && N / BN >= 8) e2.m_fast = mmiss_option("gemm_band", 5);
     const int forced = mmiss_option("gemm_group_m", -1);  // experiment knob (tools/gemm_order_sweep.py)
     if (forced >= 0 && e2.m_fast != 1) e2.m_fast = forced;
     e2.nt_out |= mmiss_option("gemm_nt", 0);

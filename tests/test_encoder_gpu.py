@@ -150,8 +150,8 @@ def test_patch14_padded_k_and_odd_token_count():
 
 
 def test_wide_mlp_takes_the_256_tile_and_matches():
-    """FC1 with N >= 4096 (the ViT-L/14 MLP width) and more than 512 rows runs on the 256x256 phase-pipelined tile;
-    its per-element k order is that of the 128-column tile, so the embeddings must not change by a bit."""
+    """FC1 with N >= 4096 (the ViT-L/14 MLP width) and more than 512 rows can run on the 256x256 phase-pipelined tile
+    (option gemm_256); its per-element k order is that of the 128-column tile, so the embeddings must not change by a bit."""
     import dataclasses
     from mmiss_amd import _lib
     from mmiss_amd.encoder import ClipEncoder, ClipShape
@@ -163,13 +163,13 @@ def test_wide_mlp_takes_the_256_tile_and_matches():
     enc.load_state_dict(W)
     rng = np.random.Generator(np.random.Philox(80))
     px = rng.standard_normal((32, 3, 56, 56), dtype=np.float32)
-    got = enc.encode_image(px)
-    assert (1 - _cos(got, co.embed_images(px, W, s))).max() < COS_TOL
-    _lib.set_option("gemm_256", 0)
+    base = enc.encode_image(px)                 # default: the 128-column tile (faster since the banded tile order)
+    assert (1 - _cos(base, co.embed_images(px, W, s))).max() < COS_TOL
+    _lib.set_option("gemm_256", 4096)
     try:
-        base = enc.encode_image(px)
+        got = enc.encode_image(px)
     finally:
-        _lib.set_option("gemm_256", 4096)
+        _lib.set_option("gemm_256", 0)
     np.testing.assert_array_equal(got, base)
 
 
