@@ -300,6 +300,7 @@ static int launch_gemm8(hipStream_t st, int epi, int bm, Gemm8Args g) {
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm8: M=%d N=%d K=%d bm=%d ld_as=%d", g.M, g.N, g.K, bm, g.ld_as);
     if (epi == MMISS_EPI8_QGELU_MXFP8 && (!g.out_scale || g.ld_os < mx_scale_row_bytes(g.N)))
         MM_FAIL(MMISS_ERR_ARG, "gemm8: the MXFP8 epilogue needs out_scale with >= %d bytes per row", mx_scale_row_bytes(g.N));
+    if (g.m_fast == 0 && g.N / 128 >= 8) g.m_fast = mmiss_option("gemm_band", 5);  // banded tile order, as gemm_bf16.h
     static const char* names[] = {"gemm_fp8_bias", "gemm_fp8_qgelu_mx", "gemm_fp8_bias_resid"};
     if (epi < 0 || epi > 2) MM_FAIL(MMISS_ERR_ARG, "gemm8: bad epilogue %d", epi);
     const int mv = g.m_valid < g.M ? g.m_valid : g.M;
