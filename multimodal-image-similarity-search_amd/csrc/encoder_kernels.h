@@ -244,7 +244,9 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const uint16_t* __
 // ------------------------------------------------------------------------------------------------
 #define ATT_VSTRIDE 144  // bytes per V row in LDS (128 + 16 pad: spreads the tr-read's 8 rows over banks)
 
-#define ATT_THREADS(NKP) ((NKP) > 4 ? 512 : 256)  // long sequences: 8 waves share one staged K/V image
+// long sequences: 8 waves share one staged K/V image. (One wave per pair of query tiles — 9 waves for the 17 tiles of
+// ViT-L/14, so that no wave walks a third pass for the one-row 17th tile — measured SLOWER: 125 vs 101 us per layer.)
+#define ATT_THREADS(NKP) ((NKP) > 4 ? 512 : 256)
 template <int NKP, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
                                                         int T, int H) {
