@@ -307,6 +307,15 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
             // tile, exponentiates it and feeds it straight to the PV MFMA - keep 2 tiles live (< 64 VGPRs); the extra
             // QK^T MFMAs are cheap next to the occupancy. Same maxima, same exp arguments, same summation order as the
             // one-pass form: bit-identical output.
+            // This form is bound by VALU issue, not by the matrix cores (PMC at T = 257: instruction issue busy 84 % of the
+            // kernel, MFMA 22 %): so the per-score vector work is kept minimal —
+            //  * raw scores (no scale): max and exp take the 1/8 scale and log2(e) in ONE fma: exp(s/8 - m/8) = exp2(s*c - m*c);
+            //  * key-validity / causal masks only on the tiles that can contain an invalid key (wave-uniform test);
+            //  * causal: key tiles entirely above the diagonal are skipped, not computed and masked.
+            const float c_exp = 0.125f * 1.4426950408889634f;
+            const int kt_end = CAUSAL ? (qt + 1 < nqt ? qt + 1 : nqt) : nqt;  // key tiles this query tile needs (nqt = ceil(T/16))
+            // tiles [0, kt_clean) hold only valid keys for every query of the tile: no mask
+            const int kt_clean = CAUSAL ? (qt < (T >> 4) ? qt : (T >> 4)) : (T >> 4);
             auto score_tile = [&](int kt) -> f32x4 {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
                 const int krow = kt * 16 + fr;
@@ -316,34 +325,40 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((chunk ^ (krow & 7)) << 4));
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
                 }
+                if (kt >= kt_clean) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 16 + 4 * fg + r;
-                    const bool ok = (key < T) && (!CAUSAL || key <= q);
-                    a[r] = ok ? a[r] * 0.125f : -INFINITY;
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 16 + 4 * fg + r;
+                        const bool ok = (key < T) && (!CAUSAL || key <= q);
+                        a[r] = ok ? a[r] : -INFINITY;
+                    }
                 }
                 return a;
             };
             float mx = -INFINITY;
 #pragma unroll 2
-            for (int kt = 0; kt < 2 * NKP; ++kt) {
+            for (int kt = 0; kt < kt_end; ++kt) {
                 const f32x4 a = score_tile(kt);
                 mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mxc = mx * c_exp;
             float l = 0.f;
             f32x4 oacc[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int tq = fr >> 2, tp = fr & 3;
+            const int ks_end = (kt_end + 1) >> 1;
 #pragma unroll 1
-            for (int ks = 0; ks < NKP; ++ks) {
-                f32x4 p0 = score_tile(2 * ks), p1 = score_tile(2 * ks + 1);
+            for (int ks = 0; ks < ks_end; ++ks) {
+                f32x4 p0 = score_tile(2 * ks), p1;
+                if (2 * ks + 1 < kt_end) p1 = score_tile(2 * ks + 1);
+                else p1 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p0[r] = __expf(p0[r] - mx); l += p0[r]; }
+                for (int r = 0; r < 4; ++r) { p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p0[r], c_exp, -mxc)); l += p0[r]; }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p1[r] = __expf(p1[r] - mx); l += p1[r]; }
+                for (int r = 0; r < 4; ++r) { p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p1[r], c_exp, -mxc)); l += p1[r]; }
                 u32x4 praw;
                 praw[0] = pack_bf16x2(p0[0], p0[1]);
                 praw[1] = pack_bf16x2(p0[2], p0[3]);
