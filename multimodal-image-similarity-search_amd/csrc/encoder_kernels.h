@@ -244,6 +244,84 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const uint16_t* __
 // ------------------------------------------------------------------------------------------------
 #define ATT_VSTRIDE 144  // bytes per V row in LDS (128 + 16 pad: spreads the tr-read's 8 rows over banks)
 
+// One 16-query tile of the one-pass form (T <= 128 keys: all score tiles live in registers). qf = the tile's Q fragments,
+// q = this lane's query row, (b, h) only enter through `orow` = ctx row of q at head h, column 4*fg.
+template <int NKP, bool CAUSAL>
+__device__ __forceinline__ void attention_onepass_tile(const char* sK, const char* sV, const bf16x8 (&qf)[2], int q, int T,
+                                                       int fr, int fg, uint16_t* orow) {
+    f32x4 sacc[2 * NKP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKP; ++kt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        const int krow = kt * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 4 * s + fg;
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((chunk ^ (krow & 7)) << 4));
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + 4 * fg + r;
+            const bool ok = (key < T) && (!CAUSAL || key <= q);
+            a[r] = ok ? a[r] * 0.125f : -INFINITY;
+            mx = fmaxf(mx, a[r]);
+        }
+        sacc[kt] = a;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2 * NKP; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pexp = __expf(sacc[kt][r] - mx);
+            sacc[kt][r] = pexp;
+            l += pexp;
+        }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tq = fr >> 2, tp = fr & 3;  // tr-read address role inside the 16-lane group
+#pragma unroll
+    for (int ks = 0; ks < NKP; ++ks) {
+        // B fragment: element j<4 = key 32ks + 4fg + j, j>=4 = key 32ks + 16 + 4fg + (j-4)
+        u32x4 praw;
+        praw[0] = pack_bf16x2(sacc[2 * ks][0], sacc[2 * ks][1]);
+        praw[1] = pack_bf16x2(sacc[2 * ks][2], sacc[2 * ks][3]);
+        praw[2] = pack_bf16x2(sacc[2 * ks + 1][0], sacc[2 * ks + 1][1]);
+        praw[3] = pack_bf16x2(sacc[2 * ks + 1][2], sacc[2 * ks + 1][3]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const char* a0 = sV + (32 * ks + 4 * fg + tq) * ATT_VSTRIDE + (dt * 16 + 4 * tp) * 2;
+            const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(a0));
+            const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(a0 + 16 * ATT_VSTRIDE));
+            bf16x8 vf;
+            vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+            vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+    }
+    const float inv = 1.0f / l;
+    if (q < T) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+            pk[1] = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+            *reinterpret_cast<u32x2*>(orow + dt * 16) = pk;
+        }
+    }
+}
+
 // long sequences: 8 waves share one staged K/V image. (One wave per pair of query tiles — 9 waves for the 17 tiles of
 // ViT-L/14, so that no wave walks a third pass for the one-row 17th tile — measured SLOWER: 125 vs 101 us per layer.)
 #define ATT_THREADS(NKP) ((NKP) > 4 ? 512 : 256)
@@ -393,78 +471,91 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
             }
             continue;
         }
-        f32x4 sacc[2 * NKP];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 2 * NKP; ++kt) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            const int krow = kt * 16 + fr;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int chunk = 4 * s + fg;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((chunk ^ (krow & 7)) << 4));
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + 4 * fg + r;
-                const bool ok = (key < T) && (!CAUSAL || key <= q);
-                a[r] = ok ? a[r] * 0.125f : -INFINITY;
-                mx = fmaxf(mx, a[r]);
-            }
-            sacc[kt] = a;
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2 * NKP; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pexp = __expf(sacc[kt][r] - mx);
-                sacc[kt][r] = pexp;
-                l += pexp;
-            }
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        attention_onepass_tile<NKP, CAUSAL>(sK, sV, qf, q, T, fr, fg, ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg);
+    }
+}
 
-        f32x4 oacc[4];
+// ------------------------------------------------------------------------------------------------
+// K4, short sequences at large batch: one workgroup walks HPB heads of one item. With one (item, head) per workgroup the
+// kernel is a chain of dependent latencies (PMC at B = 256, T = 50: 65 % of the wave cycles in s_waitcnt, matrix cores 9 %):
+// Q/K/V global loads, LDS writes, barrier, 1 us of arithmetic, store - 3072 workgroups of 20 KB each. Here the K/V image of
+// head h+1 (and its Q fragments) is in flight in registers while head h is computed from LDS (two LDS images, one barrier
+// per head), so a workgroup pays the load latency once instead of HPB times. Same arithmetic, bit-identical output.
+// ------------------------------------------------------------------------------------------------
+template <int NKP, bool CAUSAL, int HPB>
+__global__ __launch_bounds__(256) void attention_heads_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
+                                                              int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKP * 32;
+    constexpr int IMG = TP * (128 + ATT_VSTRIDE);  // one K + V image
+    constexpr int NIT = TP * 8 / 256;              // 16-byte chunks per thread and operand (TP % 32 == 0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int groups = H / HPB;
+    const int b = blockIdx.x / groups, h0 = (blockIdx.x - b * groups) * HPB;
+    const int dmodel = H * 64, ld = 3 * dmodel;
+    const uint16_t* item = qkv + (size_t)b * T * ld;
+    const int nqt = (T + 15) >> 4;
+
+    u32x4 kr[NIT], vr[NIT];
+    auto load_head = [&](int h) {
+        const uint16_t* base = item + h * 64;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int tq = fr >> 2, tp = fr & 3;  // tr-read address role inside the 16-lane group
-#pragma unroll
-        for (int ks = 0; ks < NKP; ++ks) {
-            // B fragment: element j<4 = key 32ks + 4fg + j, j>=4 = key 32ks + 16 + 4fg + (j-4)
-            u32x4 praw;
-            praw[0] = pack_bf16x2(sacc[2 * ks][0], sacc[2 * ks][1]);
-            praw[1] = pack_bf16x2(sacc[2 * ks][2], sacc[2 * ks][3]);
-            praw[2] = pack_bf16x2(sacc[2 * ks + 1][0], sacc[2 * ks + 1][1]);
-            praw[3] = pack_bf16x2(sacc[2 * ks + 1][2], sacc[2 * ks + 1][3]);
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const char* a0 = sV + (32 * ks + 4 * fg + tq) * ATT_VSTRIDE + (dt * 16 + 4 * tp) * 2;
-                const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(a0));
-                const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(a0 + 16 * ATT_VSTRIDE));
-                bf16x8 vf;
-                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, c = idx & 7;
+            kr[i] = u32x4{0u, 0u, 0u, 0u};
+            vr[i] = u32x4{0u, 0u, 0u, 0u};
+            if (row < T) {
+                kr[i] = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + dmodel + c * 8);
+                vr[i] = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + 2 * dmodel + c * 8);
             }
         }
-        const float inv = 1.0f / l;
-        if (q < T) {
-            uint16_t* orow = ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg;
+    };
+    auto store_head = [&](int buf) {
+        char* sK = smem + buf * IMG;
+        char* sV = sK + TP * 128;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                u32x2 pk;
-                pk[0] = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
-                pk[1] = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
-                *reinterpret_cast<u32x2*>(orow + dt * 16) = pk;
-            }
+        for (int i = 0; i < NIT; ++i) {
+            const int idx = tid + i * 256, row = idx >> 3, c = idx & 7;
+            *reinterpret_cast<u32x4*>(sK + row * 128 + ((c ^ (row & 7)) << 4)) = kr[i];
+            *reinterpret_cast<u32x4*>(sV + row * ATT_VSTRIDE + (c << 4)) = vr[i];
         }
+    };
+    auto load_q = [&](int h, int qt, bf16x8 (&qf)[2]) {
+        const int q = qt * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 raw = {0u, 0u, 0u, 0u};
+            if (q < T) raw = *reinterpret_cast<const u32x4*>(item + h * 64 + (size_t)q * ld + s * 32 + fg * 8);
+            qf[s] = __builtin_bit_cast(bf16x8, raw);
+        }
+    };
+
+    bf16x8 qf[2], qn[2];
+    load_q(h0, wave, qf);
+    load_head(h0);
+    store_head(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int hh = 0; hh < HPB; ++hh) {
+        const int h = h0 + hh, cur = hh & 1;
+        if (hh + 1 < HPB) {  // next head's operands fly during this head's arithmetic
+            load_q(h + 1, wave, qn);
+            load_head(h + 1);
+        }
+        const char* sK = smem + cur * IMG;
+        const char* sV = sK + TP * 128;
+        for (int qt = wave; qt < nqt; qt += 4) {
+            const int q = qt * 16 + fr;
+            if (qt != wave) load_q(h, qt, qf);  // (T > 64: a wave's second tile)
+            attention_onepass_tile<NKP, CAUSAL>(sK, sV, qf, q, T, fr, fg, ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg);
+        }
+        if (hh + 1 < HPB) {
+            store_head(cur ^ 1);  // image cur^1 was last read before the previous barrier
+            qf[0] = qn[0];
+            qf[1] = qn[1];
+        }
+        __syncthreads();
     }
 }
 
@@ -550,12 +641,57 @@ static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int 
     return MMISS_OK;
 }
 
+template <int NKP, int HPB>
+static int launch_attention_heads(hipStream_t st, const void* qkv, void* ctx, int B, int T, int H, bool causal) {
+    const int lds = 2 * NKP * 32 * (128 + ATT_VSTRIDE);
+    const dim3 grid(B * (H / HPB));
+    if (causal) {
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_heads_kernel<NKP, true, HPB>), lds));
+        hipLaunchKernelGGL((attention_heads_kernel<NKP, true, HPB>), grid, dim3(256), lds, st, (const uint16_t*)qkv,
+                           (uint16_t*)ctx, T, H);
+    } else {
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_heads_kernel<NKP, false, HPB>), lds));
+        hipLaunchKernelGGL((attention_heads_kernel<NKP, false, HPB>), grid, dim3(256), lds, st, (const uint16_t*)qkv,
+                           (uint16_t*)ctx, T, H);
+    }
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+template <int NKP>
+static int launch_attention_heads_hpb(hipStream_t st, int hpb, const void* qkv, void* ctx, int B, int T, int H, bool causal) {
+    switch (hpb) {
+        case 2: return launch_attention_heads<NKP, 2>(st, qkv, ctx, B, T, H, causal);
+        case 3: return launch_attention_heads<NKP, 3>(st, qkv, ctx, B, T, H, causal);
+        case 4: return launch_attention_heads<NKP, 4>(st, qkv, ctx, B, T, H, causal);
+        default: return launch_attention_heads<NKP, 6>(st, qkv, ctx, B, T, H, causal);
+    }
+}
+
 static int launch_attention(hipStream_t st, const void* qkv, void* ctx, int B, int T, int H, bool causal) {
     if (B <= 0) return MMISS_OK;
     if (T <= 0 || T > 288 || H <= 0) MM_FAIL(MMISS_ERR_UNSUPPORTED, "attention: T=%d (1..288), H=%d", T, H);
     const int nkp = (T + 31) / 32;
     // algorithmic flops: QK^T and PV, unpadded, full (non-causal) count as SURVEY.md §8(d) does
     MM_PROF("attention", st, 4.0 * B * H * (double)T * T * 64, (double)B * T * H * 64 * 2 * 4);
+    // short sequences, large batch: several heads per workgroup (attention_heads_kernel) while >= 512 workgroups remain.
+    // Option att_hpb: 0 = automatic, 1 = never, 2/3/4/6 = forced (if it divides H)
+    if (nkp <= 4) {
+        int hpb = mmiss_option("att_hpb", 0);
+        if (hpb == 0) {
+            hpb = 1;
+            for (int c : {6, 4, 3, 2})
+                if (H % c == 0 && (int64_t)B * (H / c) >= 512) { hpb = c; break; }
+        }
+        if ((hpb == 2 || hpb == 3 || hpb == 4 || hpb == 6) && H % hpb == 0) {
+            switch (nkp) {
+                case 1: return launch_attention_heads_hpb<1>(st, hpb, qkv, ctx, B, T, H, causal);
+                case 2: return launch_attention_heads_hpb<2>(st, hpb, qkv, ctx, B, T, H, causal);
+                case 3: return launch_attention_heads_hpb<3>(st, hpb, qkv, ctx, B, T, H, causal);
+                default: return launch_attention_heads_hpb<4>(st, hpb, qkv, ctx, B, T, H, causal);
+            }
+        }
+    }
     switch (nkp) {
         case 1: return launch_attention_nkp<1>(st, qkv, ctx, B, T, H, causal);
         case 2: return launch_attention_nkp<2>(st, qkv, ctx, B, T, H, causal);
