@@ -137,7 +137,8 @@ template <int EPI, int JT>
 // and each finalises 1/stat_parts of the rows' statistics; a workgroup barrier publishes them (all waves call the epilogue).
 __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4][JT], int m_wave, int n_wave, char* patch,
                                               int lane, char* stat_area = nullptr, int stat_part = 0, int stat_parts = 1,
-                                              const float* pre_stats = nullptr) {
+                                              const float* pre_stats = nullptr,
+                                              const f32x4 (*pre_resid)[2][2] = nullptr) {
     const int fr = lane & 15, fg = lane >> 4;
     const int rrow = lane >> 3, rchunk = lane & 7;  // read-back role: row (of 8) and 16-byte chunk (of 8)
     constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
@@ -187,7 +188,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
             for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch)
-                    resid[j][rh][ch] = *reinterpret_cast<const f32x4*>(
+                    resid[j][rh][ch] = pre_resid ? pre_resid[j][rh][ch]   // (already fetched before the K loop)
+                                                 : *reinterpret_cast<const f32x4*>(
                         reinterpret_cast<const float*>(ep.out) + (size_t)(m_wave + j * 16 + rh * 8 + rrow) * ep.ldo + n_wave +
                         ch * 32 + rchunk * 4);
     }
@@ -372,6 +374,26 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
             ln_row_stats(ep, (int64_t)bm * BM + (wave / NWN) * (BM / NWM) + r, pre_stats[0], pre_stats[1]);
     }
 
+    // ---- residual epilogue: the tile's residual rows are fetched NOW, so that the read half of the epilogue's traffic
+    // (39 MB per launch at 12800 x 768) flies under the whole K loop instead of after it. 16 * JT more live VGPRs in the
+    // loop: done for tile heights up to 160 rows (223 of the 256 registers two waves per SIMD allow), not for 192.
+    constexpr bool PRE_RESID = (EPI == MMISS_EPI_BIAS_RESID_F32) && !ALN && NWN == 2 && NWM == 2 && JT <= 5;
+    f32x4 pre_resid[PRE_RESID ? JT : 1][2][2];
+    if constexpr (PRE_RESID) {
+        if (gridDim.y == 1) {  // (split-K launches use the F32 epilogue, never this one)
+            const int rrow = lane >> 3, rchunk = lane & 7;
+            const float* xo = reinterpret_cast<const float*>(ep.out) +
+                              (size_t)(bm * BM + (wave / NWN) * (BM / NWM) + rrow) * ep.ldo + bn * BN + (wave % NWN) * 64 + rchunk * 4;
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch)
+                        pre_resid[j][rh][ch] = *reinterpret_cast<const f32x4*>(xo + (size_t)(j * 16 + rh * 8) * ep.ldo + ch * 32);
+        }
+    }
+
     // ---- ALN: per-row (mean, rstd) from the partial sums, register staging of the f32 tile
     const int xc8 = tid & 7, xr0 = tid >> 3;
     float ln_mean[RPT], ln_rstd[RPT];
@@ -531,7 +553,8 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
     // all waves are past the loop's last barrier: the staging buffers are dead, each wave takes a private patch
     // folded LayerNorm: the NWN waves of one wm share their rows' statistics (one area per wm, each wave finalises a share)
     gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / NWM), bn * BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
-                           smem + NWAVES * EPI_PATCH_BYTES + wm * (JT * 16 * 8), wn, NWN, FOLD_EPI ? pre_stats : nullptr);
+                           smem + NWAVES * EPI_PATCH_BYTES + wm * (JT * 16 * 8), wn, NWN, FOLD_EPI ? pre_stats : nullptr,
+                           PRE_RESID ? pre_resid : nullptr);
 }
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
