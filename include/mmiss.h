@@ -102,7 +102,12 @@ int mmiss_encoder_set_precision(mmiss_encoder* enc, int32_t precision);
  * use_own != 0 (the default after create): calls run on the handle's private stream and return after the
  * work has finished (host-synchronous). use_own == 0: calls are enqueued on the caller's hipStream_t
  * (passed as void*; NULL = the legacy default stream) and return without synchronising unless an
- * input or output lives in host memory.
+ * input or output lives in host memory. Changing the stream waits for the work the handle's LAST call left on the
+ * stream being left (its workspaces are reused), not for anything else the caller has queued there since.
+ * Threads: every call locks its handle, but the stream is handle state — a thread that sets the stream and then calls
+ * must keep other threads off that handle in between (the Python wrappers hold a per-handle lock around the pair);
+ * different handles never interact (several batches in flight: one encoder handle per host thread / stream,
+ * mmiss_amd/pipeline.py).
  */
 int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream, int32_t use_own);
 

@@ -81,6 +81,8 @@ struct mmiss_encoder {
     hipStream_t own_stream = nullptr;
     hipStream_t user_stream = nullptr;
     bool has_user_stream = false;
+    hipEvent_t done_ev = nullptr;  // end of the last call that returned with work queued on a caller's stream
+    bool async_pending = false;
     std::mutex mu;
     bool finalized = false;
     bool record_taps = false;
@@ -446,7 +448,13 @@ int encode_text_chunk(mmiss_encoder* e, const int32_t* ids_dev, int B, int T, fl
 }
 
 int finish_call(mmiss_encoder* e, hipStream_t st, bool must_sync) {
-    if (must_sync || !e->has_user_stream) MM_HIP(hipStreamSynchronize(st));
+    if (must_sync || !e->has_user_stream) {
+        MM_HIP(hipStreamSynchronize(st));
+    } else {
+        if (!e->done_ev) MM_HIP(hipEventCreateWithFlags(&e->done_ev, hipEventDisableTiming));
+        MM_HIP(hipEventRecord(e->done_ev, st));
+        e->async_pending = true;
+    }
     return MMISS_OK;
 }
 
@@ -598,6 +606,7 @@ extern "C" int mmiss_encoder_destroy(mmiss_encoder* enc) {
     (void)hipDeviceSynchronize();
     if (enc->own_stream) (void)hipStreamDestroy(enc->own_stream);
     if (enc->rz_copied) (void)hipEventDestroy(enc->rz_copied);
+    if (enc->done_ev) (void)hipEventDestroy(enc->done_ev);
     if (enc->copy_stream) (void)hipStreamDestroy(enc->copy_stream);
     for (int i = 0; i < 2; ++i) {
         if (enc->ev_copied[i]) (void)hipEventDestroy(enc->ev_copied[i]);
@@ -614,9 +623,11 @@ extern "C" int mmiss_encoder_set_stream(mmiss_encoder* enc, void* hip_stream, in
     hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
     const bool next_user = use_own == 0;
     if (next_user != enc->has_user_stream || (next_user && next != enc->user_stream)) {
-        // the handle's workspaces are shared by consecutive calls: drain the stream being left
+        // the handle's workspaces are shared by consecutive calls: wait for what the last call left on the stream being
+        // left — that work only, not whatever else the caller has queued there since (calls on the own stream return drained)
         MM_TRY(mmiss_use_device(enc->device));
-        MM_HIP(hipStreamSynchronize(enc->stream()));
+        if (enc->async_pending) MM_HIP(hipEventSynchronize(enc->done_ev));
+        enc->async_pending = false;
     }
     enc->user_stream = next;
     enc->has_user_stream = next_user;

@@ -9,6 +9,10 @@ struct mmiss_index {
     int dim = 0, dtype = MMISS_F32, device = 0, elt = 4;
     hipStream_t own_stream = nullptr, user_stream = nullptr;
     bool has_user_stream = false;
+    // a call that returns with work still queued on a caller's stream (device outputs) marks its end with this event;
+    // switching streams waits for exactly that work, not for whatever else the caller has put on the stream since
+    hipEvent_t done_ev = nullptr;
+    bool async_pending = false;
     std::mutex mu;
     int64_t count = 0, capacity = 0;
     DevBuf rows, labels_d;
@@ -169,14 +173,20 @@ extern "C" int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device
         delete ix;
         MM_FAIL(MMISS_ERR_HIP, "hipStreamCreate failed");
     }
-    if (hipHostMalloc(reinterpret_cast<void**>(&ix->nflag_h), 64, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&ix->nflag_h), 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ix->done_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(ix->own_stream);
+        if (ix->nflag_h) (void)hipHostFree(ix->nflag_h);
         delete ix;
-        MM_FAIL(MMISS_ERR_HIP, "hipHostMalloc failed");
+        MM_FAIL(MMISS_ERR_HIP, "hipHostMalloc / hipEventCreate failed");
     }
     if (capacity_hint > 0) {
         int rc = index_reserve(ix, capacity_hint, ix->own_stream);
-        if (rc != MMISS_OK) { (void)hipStreamDestroy(ix->own_stream); (void)hipHostFree(ix->nflag_h); delete ix; return rc; }
+        if (rc != MMISS_OK) {
+            (void)hipStreamDestroy(ix->own_stream); (void)hipHostFree(ix->nflag_h); (void)hipEventDestroy(ix->done_ev);
+            delete ix;
+            return rc;
+        }
     }
     *out = ix;
     return MMISS_OK;
@@ -188,6 +198,7 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
     (void)hipDeviceSynchronize();
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     if (ix->nflag_h) (void)hipHostFree(ix->nflag_h);
+    if (ix->done_ev) (void)hipEventDestroy(ix->done_ev);
     delete ix;
     return MMISS_OK;
 }
@@ -198,9 +209,11 @@ extern "C" int mmiss_index_set_stream(mmiss_index* ix, void* hip_stream, int32_t
     hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
     const bool next_user = use_own == 0;
     if (next_user != ix->has_user_stream || (next_user && next != ix->user_stream)) {
-        // the handle's workspaces are shared by consecutive calls: drain the stream being left
+        // the handle's workspaces are shared by consecutive calls: wait for what the last call left on the stream being
+        // left (calls on the handle's own stream, and calls with host outputs, return drained)
         MM_TRY(mmiss_use_device(ix->device));
-        MM_HIP(hipStreamSynchronize(ix->stream()));
+        if (ix->async_pending) MM_HIP(hipEventSynchronize(ix->done_ev));
+        ix->async_pending = false;
     }
     ix->user_stream = next;
     ix->has_user_stream = next_user;
@@ -735,8 +748,11 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
             MM_TRY(copy_out());
             MM_HIP(hipStreamSynchronize(st));
         }
-    } else if (!ix->has_user_stream && !guard) {
-        MM_HIP(hipStreamSynchronize(st));
+    } else if (!ix->has_user_stream) {
+        if (!guard) MM_HIP(hipStreamSynchronize(st));
+    } else {
+        MM_HIP(hipEventRecord(ix->done_ev, st));
+        ix->async_pending = true;
     }
     return MMISS_OK;
 }

@@ -7,6 +7,7 @@ HF state_dict key layout (SURVEY.md §8 a-W), so a local HF checkpoint loads unc
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass, asdict
 from typing import Dict, Iterable, Optional, Tuple
 
@@ -169,6 +170,7 @@ class ClipEncoder:
         h = C.c_void_p()
         _lib.check(self._lib.mmiss_encoder_create(C.byref(cfg), self.device, C.byref(h)))
         self._h = h
+        self._call_lock = threading.Lock()
         self._finalized = False
         self.precision = "bf16"
         if precision != "bf16":
@@ -240,9 +242,10 @@ class ClipEncoder:
             pixels = pixels.contiguous()
         B = int(pixels.shape[0])
         out = self._out(pixels, B) if out is None else out
-        self._sync_stream(pixels)
-        fn = self._lib.mmiss_encode_image_u8 if is_u8 else self._lib.mmiss_encode_image
-        _lib.check(fn(self._h, _lib.ptr(pixels), B, _lib.ptr(out)))
+        with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
+            self._sync_stream(pixels)
+            fn = self._lib.mmiss_encode_image_u8 if is_u8 else self._lib.mmiss_encode_image
+            _lib.check(fn(self._h, _lib.ptr(pixels), B, _lib.ptr(out)))
         return out
 
     @staticmethod
@@ -271,9 +274,10 @@ class ClipEncoder:
         out = np.empty((B, S, S, 3), dtype=np.uint8)
         if B == 0:
             return out
-        self._sync_stream(blob)
-        _lib.check(self._lib.mmiss_resize_crop_rgb(self._h, _lib.ptr(blob), blob.size, _lib.ptr(off), _lib.ptr(hs),
-                                                   _lib.ptr(ws), B, _lib.ptr(out)))
+        with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
+            self._sync_stream(blob)
+            _lib.check(self._lib.mmiss_resize_crop_rgb(self._h, _lib.ptr(blob), blob.size, _lib.ptr(off), _lib.ptr(hs),
+                                                       _lib.ptr(ws), B, _lib.ptr(out)))
         return out
 
     def encode_image_rgb(self, images, out=None) -> np.ndarray:
@@ -299,9 +303,10 @@ class ClipEncoder:
         out = self._out(blob, B) if out is None else out
         if B == 0:
             return out
-        self._sync_stream(blob)
-        _lib.check(self._lib.mmiss_encode_image_rgb(self._h, _lib.ptr(blob), int(blob.numel() if _is_torch(blob) else blob.size),
-                                                    _lib.ptr(off), _lib.ptr(hs), _lib.ptr(ws), B, _lib.ptr(out)))
+        with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
+            self._sync_stream(blob)
+            _lib.check(self._lib.mmiss_encode_image_rgb(self._h, _lib.ptr(blob), int(blob.numel() if _is_torch(blob) else blob.size),
+                                                        _lib.ptr(off), _lib.ptr(hs), _lib.ptr(ws), B, _lib.ptr(out)))
         return out
 
     def encode_text(self, input_ids, out=None, trim_padding: bool = True):
@@ -327,8 +332,9 @@ class ClipEncoder:
             raise ValueError("input_ids must be [B,T]")
         B, T = int(ids.shape[0]), int(ids.shape[1])
         out = self._out(ids, B) if out is None else out
-        self._sync_stream(ids)
-        _lib.check(self._lib.mmiss_encode_text(self._h, _lib.ptr(ids), B, T, _lib.ptr(out)))
+        with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
+            self._sync_stream(ids)
+            _lib.check(self._lib.mmiss_encode_text(self._h, _lib.ptr(ids), B, T, _lib.ptr(out)))
         return out
 
     # ------------------------------------------------------------------ debug

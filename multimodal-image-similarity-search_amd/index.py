@@ -7,6 +7,7 @@ smallest cosine distance 1 - cos, ascending, ties by label ascending.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Tuple
 
 import numpy as np
@@ -30,6 +31,7 @@ class FlatIndex:
         h = C.c_void_p()
         _lib.check(self._lib.mmiss_index_create(self.dim, self.dtype, self.device, int(capacity), C.byref(h)))
         self._h = h
+        self._call_lock = threading.Lock()
 
     # ------------------------------------------------------------------ helpers
     def _vecs(self, v):
@@ -57,14 +59,16 @@ class FlatIndex:
         lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
         if lab.shape[0] != v.shape[0]:
             raise ValueError("labels and vectors differ in length")
-        self._sync_stream(v)
-        _lib.check(self._lib.mmiss_index_add(self._h, _lib.ptr(v), lab.ctypes.data, int(v.shape[0])))
+        with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
+            self._sync_stream(v)
+            _lib.check(self._lib.mmiss_index_add(self._h, _lib.ptr(v), lab.ctypes.data, int(v.shape[0])))
 
     def update(self, labels, vecs) -> None:
         v = self._vecs(vecs)
         lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
-        self._sync_stream(v)
-        _lib.check(self._lib.mmiss_index_update(self._h, lab.ctypes.data, _lib.ptr(v), int(v.shape[0])))
+        with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
+            self._sync_stream(v)
+            _lib.check(self._lib.mmiss_index_update(self._h, lab.ctypes.data, _lib.ptr(v), int(v.shape[0])))
 
     def remove(self, labels) -> int:
         lab = np.ascontiguousarray(labels, dtype=np.int64).reshape(-1)
@@ -114,8 +118,9 @@ class FlatIndex:
             lab = np.empty((Q, k), dtype=np.int64)
             dist = np.empty((Q, k), dtype=np.float32)
             cnt = np.empty((Q,), dtype=np.int32)
-        self._sync_stream(q)
-        _lib.check(self._lib.mmiss_index_query(self._h, _lib.ptr(q), Q, int(k), _lib.ptr(lab), _lib.ptr(dist), _lib.ptr(cnt)))
+        with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
+            self._sync_stream(q)
+            _lib.check(self._lib.mmiss_index_query(self._h, _lib.ptr(q), Q, int(k), _lib.ptr(lab), _lib.ptr(dist), _lib.ptr(cnt)))
         return lab, dist, cnt
 
     def guard_stats(self) -> dict:
