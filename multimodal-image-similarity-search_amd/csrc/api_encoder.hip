@@ -257,6 +257,18 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // 2064 tiles are 8.06 rounds of 256 CUs), so it is off by default. Option gemm_256 = minimum N, 0 = never.
     const int min_n256 = mmiss_option("gemm_256", 0);
     auto use256 = [&](int N) { return plain && min_n256 > 0 && N >= min_n256 && (N % 256) == 0 && (d % 64) == 0 && M > 512; };
+    // the same tile with the folded-LayerNorm epilogue, for the QKV GEMM: round 2, inside the bs-256 encode (tools/option_ab2.py)
+    // 55.4 -> 52.3 us per QKV launch (2.989 -> 2.960 ms per encode), text tower 42.4 -> 40.7 us. Taken when the tile count
+    // fills its last round of 256 CUs to >= 85 % (ViT-B/32 at 12 800 rows: 450 tiles = 88 %; its FC1 would be 600 = 78 % and
+    // measures 78 -> 84 us, so that one stays on the 128-column tiles: option gemm_256_fold_mlp). Option gemm_256_fold:
+    // -1 = this rule, 0 = never, n > 0 = from N = n whatever the fill.
+    const int min_n256f = mmiss_option("gemm_256_fold", -1);
+    auto fold256 = [&](int N) {
+        if (mode != 2 || min_n256f == 0 || (N % 256) != 0 || (d % 64) != 0 || M <= 512) return false;
+        if (min_n256f > 0) return N >= min_n256f;
+        const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256), rounds = (tiles + 255) / 256;
+        return tiles * 100 >= rounds * 256 * 85;
+    };  // (workspace rows are padded to round_up(M, 128) + 192 >= round_up(M, 256))
     // split-K scratch for the narrow long-K GEMM (FC2) while its grid is far below the CU count
     if (gemm_splitk_candidate((int64_t)((M + 127) / 128) * (d / GEMM_BN), tw.mlp))
         MM_TRY(tw.splitk.ensure((size_t)8 * (round_up(M, 128) + 192) * d * 4));  // any tile height's row padding
@@ -287,6 +299,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         if (fold) {
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
+            if (fold256(3 * d)) MM_TRY(launch_gemm256(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, padded(256), 3 * d, d));
+            else
             MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_BF16, bm_qkv, tw.xb.p, L.wqkv_f.p, ep, padded(bm_qkv), 3 * d, d));
 #ifdef MMISS_EXPERIMENTS
         } else if (fuse) {
@@ -341,6 +355,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         if (fold) {
             ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
+            if (fold256(tw.mlp) && mmiss_option("gemm_256_fold_mlp", 0)) MM_TRY(launch_gemm256(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, padded(256), tw.mlp, d));
+            else
             MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, bm_mlp, tw.xb.p, L.w1_f.p, ep, padded(bm_mlp), tw.mlp, d));
 #ifdef MMISS_EXPERIMENTS
         } else if (fuse) {

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const IN* __restrict__ 
         }
         return;
     } else {
-        gemm_epilogue<EPI, 8>(ep, acc, bm * 256 + wm * 128, bn * 256 + wn * 64, smem + wave * EPI_PATCH_BYTES, lane);
+        // (folded LayerNorm: the 4 waves of one m-half share the (mean, rstd) table of its 128 rows, behind the patches)
+        gemm_epilogue<EPI, 8>(ep, acc, bm * 256 + wm * 128, bn * 256 + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
+                              smem + 8 * EPI_PATCH_BYTES + wm * (128 * 8), wn, 4);
     }
 }
 
@@ -379,7 +381,9 @@ static int launch_gemm256_strip(hipStream_t st, const void* A, const void* W, co
 }
 
 template <typename IN, int EPI>
-static int launch_gemm256_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+static int launch_gemm256_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep_in, int M, int N, int K) {
+    GemmEpi ep = ep_in;
+    if (ep.m_fast == 0) ep.m_fast = mmiss_option("gemm_band_256", 0);  // m-band tile order (tile_order), 0 = n fastest
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256_kernel<IN, EPI>), G256_LDS));
     const int nwg = (M / 256) * (N / 256);
     hipLaunchKernelGGL((gemm256_kernel<IN, EPI>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
@@ -389,21 +393,27 @@ static int launch_gemm256_inst(hipStream_t st, const void* A, const void* W, con
 }
 
 // bf16 GEMM on the 256x256 tile: M, N multiples of 256, K a multiple of 64; epilogues F32 / BIAS_BF16 /
-// BIAS_QGELU_BF16 / BIAS_RESID_F32.
+// BIAS_QGELU_BF16 / BIAS_RESID_F32 and the folded-LayerNorm pair LNFOLD_BF16 / LNFOLD_QGELU_BF16 (ep.ln_stats, ep.aux set).
 static int launch_gemm256(hipStream_t st, int epi, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || (M % 256) || (N % 256) || (K % GEMM_BK))
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256: M=%d N=%d K=%d must be multiples of 256/256/%d", M, N, K, GEMM_BK);
+    const bool fold = epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16;
     static const char* names[] = {"gemm_bf16_f32", "gemm_bf16_bias", "gemm_bf16_bias_qgelu", "gemm_bf16_bias_resid"};
-    if (epi < 0 || epi > 3) MM_FAIL(MMISS_ERR_ARG, "gemm256: bad epilogue %d", epi);
-    const int out_elt = (epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16) ? 2 : 4;
+    if (!fold && (epi < 0 || epi > 3)) MM_FAIL(MMISS_ERR_ARG, "gemm256: bad epilogue %d", epi);
+    if (fold && (!ep.ln_stats || !ep.aux || !ep.bias || ep.ln_parts * 64 != K))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256 fold: K=%d parts=%d", K, ep.ln_parts);
+    const int out_elt = (epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16 || fold) ? 2 : 4;
     const int mv = ep.m_valid < M ? ep.m_valid : M;
     const double bytes = 2.0 * ((double)mv * K + (double)N * K) +
                          (double)out_elt * mv * N * (epi == MMISS_EPI_BIAS_RESID_F32 ? 2 : 1);
-    MM_PROF(names[epi], st, gemm_flops(mv, N, K), bytes);
+    MM_PROF(fold ? (epi == MMISS_EPI_LNFOLD_BF16 ? "gemm_bf16_lnfold_bias" : "gemm_bf16_lnfold_qgelu") : names[epi], st,
+            gemm_flops(mv, N, K), bytes);
     switch (epi) {
         case MMISS_EPI_F32: return launch_gemm256_inst<__bf16, MMISS_EPI_F32>(st, A, W, ep, M, N, K);
         case MMISS_EPI_BIAS_BF16: return launch_gemm256_inst<__bf16, MMISS_EPI_BIAS_BF16>(st, A, W, ep, M, N, K);
         case MMISS_EPI_BIAS_QGELU_BF16: return launch_gemm256_inst<__bf16, MMISS_EPI_BIAS_QGELU_BF16>(st, A, W, ep, M, N, K);
+        case MMISS_EPI_LNFOLD_BF16: return launch_gemm256_inst<__bf16, MMISS_EPI_LNFOLD_BF16>(st, A, W, ep, M, N, K);
+        case MMISS_EPI_LNFOLD_QGELU_BF16: return launch_gemm256_inst<__bf16, MMISS_EPI_LNFOLD_QGELU_BF16>(st, A, W, ep, M, N, K);
         default: return launch_gemm256_inst<__bf16, MMISS_EPI_BIAS_RESID_F32>(st, A, W, ep, M, N, K);
     }
 }

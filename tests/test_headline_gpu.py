@@ -241,3 +241,28 @@ def test_config3_q1024_blended_against_a_1p25m_row_shard():
     np.testing.assert_array_equal(lab[qs], ol)
     np.testing.assert_array_equal(dist[qs].view(np.uint32), od.view(np.uint32))
     idx.close()
+
+
+def test_b32_bs256_fold_epilogue_on_the_256_tile(b32_256):
+    """The folded-LayerNorm epilogue on the 256 x 256 phase-pipelined tile (options gemm_256_fold / gemm_256_fold_mlp;
+    off by default, tools/option_ab.py decides): same bar against the oracle, and against the default tiles the same
+    fp32 function with the same bf16 operand roundings (only the f32 summation order inside a K-tile differs)."""
+    from mmiss_amd import _lib
+
+    enc, small, W, co = b32_256
+    s = co.VIT_B32
+    rng = np.random.Generator(np.random.Philox(77))
+    px = rng.standard_normal((256, 3, 224, 224), dtype=np.float32)
+    px[9] = px[9] * 0.05 + 4.0
+    base = enc.encode_image(px)
+    _lib.set_option("gemm_256_fold", 2304)
+    _lib.set_option("gemm_256_fold_mlp", 1)
+    try:
+        out, kern = _kernels_of(lambda: enc.encode_image(px))
+    finally:
+        _lib.set_option("gemm_256_fold", 0)
+        _lib.set_option("gemm_256_fold_mlp", 0)
+    assert kern.get("gemm_bf16_lnfold_bias", 0) == 12 and kern.get("gemm_bf16_lnfold_qgelu", 0) == 11, kern
+    sub = np.concatenate([[9], np.arange(0, 256, 17)])
+    assert (1 - _cos(out[sub], co.embed_images(px[sub], W, s))).max() < COS_TOL
+    assert (1 - _cos(out, base)).max() < 1e-5
