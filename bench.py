@@ -41,6 +41,7 @@ HBM_PEAK_GBS = 8000.0           # spec; ~6.3 TB/s achievable (same guide)
 KERNEL_SYMBOL = {  # libmmiss kernel class -> symbol as rocprofv3 --kernel-trace prints it
     "gemm_bf16_f32": "gemm16_kernel<__bf16,BM,0>", "gemm_bf16_bias": "gemm16_kernel<__bf16,BM,1>",
     "gemm_bf16_bias_qgelu": "gemm16_kernel<__bf16,BM,2>", "gemm_bf16_bias_resid": "gemm16_kernel<__bf16,BM,3>",
+    "gemm_bf16_bias_resid16": "gemm16_kernel<__bf16,BM,9>",
     "gemm_bf16_lnfold_bias": "gemm256_kernel<__bf16,7> (>= 85 % tile fill) / gemm16_kernel<__bf16,BM,7>", "gemm_bf16_lnfold_qgelu": "gemm16_kernel<__bf16,BM,8>",
     "gemm_bf16_patch": "gemm16_kernel<__bf16,BM,4>", "score_gemm_f16": "gemm16_kernel<_Float16,128,5>",
     "attention": "attention_kernel<2,false>",
@@ -484,7 +485,10 @@ def main():
                        "flops_per_image": 8.818e9, "flops_per_image_executed": 8.298e9,
                        "pruning": "last layer: out-proj + MLP on the pooled (CLS) rows only",
                        "layernorm": "folded into the QKV / FC1 GEMMs (automatic from 6000 rows per call): the residual GEMM's "
-                                    "epilogue also writes the bf16 copy and the row statistics of the new residual rows",
+                                    "epilogue also writes the row statistics of the new residual rows",
+                       "residual_stream": "bf16 in that mode (read-modify-write of the bf16 rows, f32 accumulate + add, one "
+                                          "rounding per add; 1 - cos vs the fp32 oracle 5e-5, tests/test_headline_gpu.py); "
+                                          "set_precision('bf16-f32resid') keeps it f32 (5e-6, 4-5 % slower)",
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),

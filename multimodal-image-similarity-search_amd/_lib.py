@@ -19,6 +19,7 @@ MMISS_F32 = 0
 MMISS_F16 = 1
 MMISS_PREC_BF16 = 0
 MMISS_PREC_FP8 = 1
+MMISS_PREC_BF16_F32RESID = 2
 
 EPI_F32, EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_PATCH_F32 = range(5)
 

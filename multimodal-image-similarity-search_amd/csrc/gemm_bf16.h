@@ -48,6 +48,12 @@ struct GemmEpi {
 // (mean_m, rstd_m from ep.ln_stats; c in ep.aux; b' in ep.bias). 7: bf16 out, 8: + QuickGELU.
 #define MMISS_EPI_LNFOLD_BF16 7
 #define MMISS_EPI_LNFOLD_QGELU_BF16 8
+// internal: the residual stream itself kept in bf16 (ep.out = bf16 [M, ldo], updated in place):
+//   out = bf16( f32(out) + acc + bias ),  ep.stats_out = partial (sum, sumsq) of the ROUNDED new rows per 64 columns.
+// The f32 stream of BIAS_RESID_F32 costs 78.6 MB of read-modify-write + a 19.7 MB bf16 copy per launch at 12800 x 768;
+// this form moves 2 x 19.7 MB. Each add rounds the stream to 8 significant bits: 1 - cos vs the fp32 oracle goes from
+// ~5e-6 to 3-8e-5 (tolerance 1e-3) — see DESIGN.md "bf16 residual stream".
+#define MMISS_EPI_BIAS_RESID_BF16 9
 
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -138,13 +144,14 @@ template <int EPI, int JT>
 __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4][JT], int m_wave, int n_wave, char* patch,
                                               int lane, char* stat_area = nullptr, int stat_part = 0, int stat_parts = 1,
                                               const float* pre_stats = nullptr,
-                                              const f32x4 (*pre_resid)[2][2] = nullptr) {
+                                              const f32x4 (*pre_resid)[2][2] = nullptr,
+                                              const u32x4 (*pre_resid16)[2] = nullptr) {
     const int fr = lane & 15, fg = lane >> 4;
     const int rrow = lane >> 3, rchunk = lane & 7;  // read-back role: row (of 8) and 16-byte chunk (of 8)
     constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
     constexpr bool OUT_BF16 = (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16 || FOLD);
     f32x4 bias[4], cvec[4];
-    if constexpr (OUT_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32) {
+    if constexpr (OUT_BF16 || EPI == MMISS_EPI_BIAS_RESID_F32 || EPI == MMISS_EPI_BIAS_RESID_BF16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + n_wave + i * 16 + 4 * fg);
     }
@@ -193,6 +200,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
                         reinterpret_cast<const float*>(ep.out) + (size_t)(m_wave + j * 16 + rh * 8 + rrow) * ep.ldo + n_wave +
                         ch * 32 + rchunk * 4);
     }
+    // BIAS_RESID_BF16: lane (rrow, rchunk) owns 8 consecutive columns of 8 rows per 16-row sub-tile: one 16-byte load /
+    // store per row half, whole 128-byte row segments per 8 lanes
+    u32x4 resid16[EPI == MMISS_EPI_BIAS_RESID_BF16 ? JT : 1][2];
+    if constexpr (EPI == MMISS_EPI_BIAS_RESID_BF16) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+                resid16[j][rh] = pre_resid16 ? pre_resid16[j][rh]
+                                             : *reinterpret_cast<const u32x4*>(
+                    reinterpret_cast<const uint16_t*>(ep.out) + (size_t)(m_wave + j * 16 + rh * 8 + rrow) * ep.ldo + n_wave +
+                    rchunk * 8);
+    }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         // ---- transpose-in: lane (fr = row, fg) owns columns i*16 + 4*fg .. +3
@@ -217,7 +237,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v = acc[i][j];
-                if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) v += bias[i];
+                if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32 || EPI == MMISS_EPI_BIAS_RESID_BF16) v += bias[i];
                 *reinterpret_cast<f32x4*>(patch + fr * 272 + i * 64 + fg * 16) = v;
             }
         }
@@ -235,6 +255,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& ep, f32x4 (&acc)[4]
                     u32x4* po = reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_wave + rchunk * 8);
                     if (ep.nt_out & 2) __builtin_nontemporal_store(v, po);
                     else *po = v;
+                }
+            } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_BF16) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + row * 272 + rchunk * 32);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + row * 272 + rchunk * 32 + 16);
+                const u32x4 old = resid16[j][rh];
+                float y[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[2 * e] = __uint_as_float(old[e] << 16) + (e < 2 ? lo[2 * e] : hi[2 * e - 4]);
+                    y[2 * e + 1] = __uint_as_float(old[e] & 0xFFFF0000u) + (e < 2 ? lo[2 * e + 1] : hi[2 * e - 3]);
+                }
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(y[2 * e], y[2 * e + 1]);
+                if (m < ep.m_valid)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n_wave + rchunk * 8) = pk;
+                if (ep.stats_out) {  // statistics of what was STORED (the rounded rows are the residual stream from here on)
+                    float rs = 0.f, rq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = __uint_as_float(pk[e] << 16), b = __uint_as_float(pk[e] & 0xFFFF0000u);
+                        rs += a + b;
+                        rq += a * a + b * b;
+                    }
+                    rs += __shfl_xor(rs, 1); rq += __shfl_xor(rq, 1);
+                    rs += __shfl_xor(rs, 2); rq += __shfl_xor(rq, 2);
+                    rs += __shfl_xor(rs, 4); rq += __shfl_xor(rq, 4);
+                    if (rchunk == 0 && m < ep.m_valid) {
+                        float* so = ep.stats_out + ((size_t)m * (ep.ldo >> 6) + (n_wave >> 6)) * 2;
+                        so[0] = rs;
+                        so[1] = rq;
+                    }
                 }
             } else {
                 float rs = 0.f, rq = 0.f;  // this lane's share of the row's (sum, sumsq) over the wave's 64 columns
@@ -392,6 +444,20 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
                     for (int ch = 0; ch < 2; ++ch)
                         pre_resid[j][rh][ch] = *reinterpret_cast<const f32x4*>(xo + (size_t)(j * 16 + rh * 8) * ep.ldo + ch * 32);
         }
+    }
+
+    // (bf16 residual stream: 8 registers per 16-row sub-tile instead of 16 — every tile height prefetches)
+    constexpr bool PRE_RESID16 = (EPI == MMISS_EPI_BIAS_RESID_BF16) && !ALN && NWN == 2 && NWM == 2;
+    u32x4 pre_resid16[PRE_RESID16 ? JT : 1][2];
+    if constexpr (PRE_RESID16) {
+        const int rrow = lane >> 3, rchunk = lane & 7;
+        const uint16_t* xo = reinterpret_cast<const uint16_t*>(ep.out) +
+                             (size_t)(bm * BM + (wave / NWN) * (BM / NWM) + rrow) * ep.ldo + bn * BN + (wave % NWN) * 64 + rchunk * 8;
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+                pre_resid16[j][rh] = *reinterpret_cast<const u32x4*>(xo + (size_t)(j * 16 + rh * 8) * ep.ldo);
     }
 
     // ---- ALN: per-row (mean, rstd) from the partial sums, register staging of the f32 tile
@@ -554,7 +620,7 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
     // folded LayerNorm: the NWN waves of one wm share their rows' statistics (one area per wm, each wave finalises a share)
     gemm_epilogue<EPI, JT>(ep, acc, bm * BM + wm * (BM / NWM), bn * BN + wn * 64, smem + wave * EPI_PATCH_BYTES, lane,
                            smem + NWAVES * EPI_PATCH_BYTES + wm * (JT * 16 * 8), wn, NWN, FOLD_EPI ? pre_stats : nullptr,
-                           PRE_RESID ? pre_resid : nullptr);
+                           PRE_RESID ? pre_resid : nullptr, PRE_RESID16 ? pre_resid16 : nullptr);
 }
 
 static inline double gemm_flops(int M, int N, int K) { return 2.0 * M * N * K; }
@@ -656,6 +722,25 @@ static int launch_gemm_fold(hipStream_t st, int epi, int bm, const void* A, cons
     }
 #undef GEMM_FOLD_CASE
     MM_FAIL(MMISS_ERR_ARG, "gemm_fold: unsupported tile height %d", bm);
+}
+
+// Residual GEMM on a bf16 residual stream (epilogue 9): ep.out = the stream (bf16, read-modify-write), ep.bias set,
+// ep.stats_out optional.
+static int launch_gemm_resid16(hipStream_t st, int bm, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+    if (bm == 0) bm = 128;
+    if (M <= 0 || N <= 0 || K <= 0 || (M % bm) || (N % GEMM_BN) || (K % GEMM_BK) || !ep.out || !ep.bias)
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm_resid16: M=%d N=%d K=%d bm=%d", M, N, K, bm);
+    const int mv = ep.m_valid < M ? ep.m_valid : M;
+    const double bytes = 2.0 * ((double)mv * K + (double)N * K) + 2.0 * 2.0 * (double)mv * N;
+    char pname[48];
+    snprintf(pname, sizeof(pname), "gemm_bf16_bias_resid16_k%d", K);
+    MM_PROF(pname, st, 2.0 * mv * N * K, bytes);
+    switch (bm) {
+        case 128: return launch_gemm_inst<__bf16, 128, MMISS_EPI_BIAS_RESID_BF16>(st, A, W, ep, M, N, K);
+        case 160: return launch_gemm_inst<__bf16, 160, MMISS_EPI_BIAS_RESID_BF16>(st, A, W, ep, M, N, K);
+        case 192: return launch_gemm_inst<__bf16, 192, MMISS_EPI_BIAS_RESID_BF16>(st, A, W, ep, M, N, K);
+    }
+    MM_FAIL(MMISS_ERR_ARG, "gemm_resid16: unsupported tile height %d", bm);
 }
 
 #ifdef MMISS_EXPERIMENTS  // ln_mode 1: measured slower (342-371 TF), kept for A/B in debug builds

@@ -72,7 +72,8 @@ def test_b32_bs256_default_path_is_the_folded_one_and_matches_the_oracle(b32_256
     # the same images 16 at a time: <= 800 rows per call -> ln_mode 0
     parts, kern16 = _kernels_of(lambda: np.concatenate([small.encode_image(px[i:i + 16]) for i in range(0, 256, 16)]))
     assert "gemm_bf16_lnfold_bias" not in kern16, kern16
-    assert (1 - _cos(parts, out)).max() < 1e-4  # two bf16 roundings of the same fp32 function (measured ~2e-5)
+    assert (1 - _cos(parts, out)).max() < 2e-4  # two bf16 roundings of the same fp32 function (f32 residual stream at 16 rows,
+    # bf16 stream at 256: measured ~6e-5)
     again = enc.encode_image(px)
     np.testing.assert_array_equal(out, again)  # deterministic
 
@@ -114,7 +115,7 @@ def test_b32_text_tower_256x77_default_path(b32_256):
     d = 1 - _cos(out[sub], co.embed_texts(ids[sub], W, s))
     assert d.max() < COS_TOL, d
     parts = np.concatenate([small.encode_text(ids[i:i + 16], trim_padding=False) for i in range(0, 256, 16)])
-    assert (1 - _cos(parts, out)).max() < 1e-4  # measured 3.3e-5: two bf16 roundings of the same fp32 function
+    assert (1 - _cos(parts, out)).max() < 2e-4  # two bf16 roundings of the same fp32 function (measured ~6e-5)
 
 
 def test_hf_goldens_b32_against_gpu_output(b32_256):
@@ -265,4 +266,35 @@ def test_b32_bs256_fold_epilogue_on_the_256_tile(b32_256):
     assert kern.get("gemm_bf16_lnfold_bias", 0) == 12 and kern.get("gemm_bf16_lnfold_qgelu", 0) == 11, kern
     sub = np.concatenate([[9], np.arange(0, 256, 17)])
     assert (1 - _cos(out[sub], co.embed_images(px[sub], W, s))).max() < COS_TOL
-    assert (1 - _cos(out, base)).max() < 1e-5
+    assert (1 - _cos(out, base)).max() < 5e-5   # (a last-bit f32 difference can flip a bf16 rounding of the residual stream)
+
+
+def test_b32_bs256_bf16_residual_stream_and_the_f32_alternative(b32_256):
+    """Default at 12 800 rows: the residual stream itself in bf16 (the residual GEMMs read-modify-write the bf16 rows; every
+    add rounds the stream to 8 significant bits). Precision "bf16-f32resid" keeps the f32 stream of round 1. Both against
+    the fp32 oracle at the 1e-3 bar; the measured distances are printed (CPU simulation of the same roundings: 3-8e-5
+    against 2e-6 .. 2e-5)."""
+    enc, small, W, co = b32_256
+    s = co.VIT_B32
+    rng = np.random.Generator(np.random.Philox(78))
+    px = rng.standard_normal((256, 3, 224, 224), dtype=np.float32)
+    px[9] = px[9] * 0.05 + 4.0
+    ids = co.synthetic_text_ids(256, 77, s.t_vocab, s.eos_token_id, seed=5, bos=49406)
+    out_i, kern = _kernels_of(lambda: enc.encode_image(px))
+    out_t = enc.encode_text(ids)
+    np.testing.assert_array_equal(out_i, enc.encode_image(px))
+    assert kern.get("gemm_bf16_bias_resid16_k768", 0) == 11 and kern.get("gemm_bf16_bias_resid16_k3072", 0) == 11, kern
+    enc.set_precision("bf16-f32resid")
+    try:
+        f32_i, kern32 = _kernels_of(lambda: enc.encode_image(px))
+        f32_t = enc.encode_text(ids)
+    finally:
+        enc.set_precision("bf16")
+    assert kern32.get("gemm_bf16_bias_resid_k768", 0) == 11 and "gemm_bf16_bias_resid16_k768" not in kern32, kern32
+    sub = np.concatenate([[9], np.arange(0, 256, 17)])
+    ref_i, ref_t = co.embed_images(px[sub], W, s), co.embed_texts(ids[sub], W, s)
+    d16 = (1 - _cos(out_i[sub], ref_i)).max(), (1 - _cos(out_t[sub], ref_t)).max()
+    d32 = (1 - _cos(f32_i[sub], ref_i)).max(), (1 - _cos(f32_t[sub], ref_t)).max()
+    print("1 - cos vs oracle, bf16 residual stream: image %.2e text %.2e; f32 stream: image %.2e text %.2e" % (d16 + d32))
+    assert max(d16) < 2e-4, d16          # (the bar of the path is COS_TOL = 1e-3; this pins the measured level)
+    assert max(d32) < 6e-5, d32          # (text tower: 3.2e-5 with bf16 operands alone)

@@ -17,10 +17,11 @@ import sys
 # library kernel class -> regex over the (mangled or demangled) kernel name
 CLASSES = {
     "gemm_bf16_bias_resid": r"gemm16_kernelIDF16bLi160ELi3E",
+    "gemm_bf16_bias_resid16": r"gemm16_kernelIDF16bLi160ELi9E",
     "gemm_bf16_bias_resid_pruned": r"gemm16_kernelIDF16bLi128ELi3E",
     "gemm_bf16_bias_qgelu": r"gemm16_kernelIDF16bLi192ELi2E",
     "gemm_bf16_lnfold_qgelu": r"gemm16_kernelIDF16bLi192ELi8E",
-    "gemm_bf16_lnfold_bias": r"gemm16_kernelIDF16bLi192ELi7E",
+    "gemm_bf16_lnfold_bias": r"gemm16_kernelIDF16bLi192ELi7E|gemm256_kernelIDF16bLi7E",
     "gemm_bf16_bias": r"gemm16_kernelIDF16bLi192ELi1E",
     "gemm_bf16_patch": r"gemm16_kernelIDF16bLi160ELi4E",
     "score_gemm_f16": r"gemm256_kernelIDF16_Li5E",
@@ -32,6 +33,9 @@ CLASSES = {
 ALGORITHMIC = {  # bytes per launch the kernel must move, averaged over the shapes in the class
     # residual GEMM in the folded-LayerNorm mode (the default from 6000 rows): 130.7 MB of GEMM traffic + the bf16 copy of
     # the new residual rows (19.7 MB) + their partial LayerNorm statistics (1.2 MB) that replace the LayerNorm pass
+    # bf16 residual stream: out-proj 19.7 (A) + 1.2 (W) + 2 x 19.7 (stream) + 1.2 (stats) = 61.5 MB, FC2 78.6 + 4.7 + 39.3 + 1.2
+    # = 123.8 MB -> class average 92.7 MB
+    "gemm_bf16_bias_resid16": 92.7e6,
     "gemm_bf16_bias_resid": 151.6e6, "gemm_bf16_bias_qgelu": 103.0e6, "gemm_bf16_bias": 82.2e6,
     "gemm_bf16_lnfold_qgelu": 104.3e6, "gemm_bf16_lnfold_bias": 83.5e6,
     "scan_topk_f16": 10.24e9,
