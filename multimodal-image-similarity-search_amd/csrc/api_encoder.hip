@@ -300,18 +300,21 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     const bool prune = !e->record_taps;
     tw.pooled_compact = false;
     const bool fuse = mode == 1, fold = mode == 2;
-    // bf16 residual stream (folded mode only; needs the pruned last layer, i.e. no taps): option resid16
-    // Default in that mode (MMISS_PREC_BF16); MMISS_PREC_BF16_F32RESID or option resid16 = 0 keep the f32 stream.
+    // bf16 residual stream for the large calls (needs the pruned last layer, i.e. no taps): the residual GEMMs
+    // read-modify-write the bf16 rows; in the folded mode these rows are the A operand of the next GEMM as well, in the
+    // separate-LayerNorm mode (hidden > 768: ViT-L/14) the LayerNorm kernel reads them. Default under MMISS_PREC_BF16 from
+    // `ln_fold_min_rows` rows; MMISS_PREC_BF16_F32RESID or option resid16 = 0 keep the f32 stream (small calls always do).
     // ViT-B/32, 256 images: residual GEMMs 33.8 -> 28.5 us (K = 768), 71.4 -> 66.6 us (K = 3072), encode 3.05 -> 2.91 ms;
     // 1 - cos vs the fp32 oracle 5e-6 -> 5e-5 (tolerance 1e-3).
     const int r16opt = mmiss_option("resid16", -1);
-    const bool resid16 = fold && prune && tw.layers >= 1 &&
-                         (r16opt >= 0 ? r16opt != 0 : e->precision != MMISS_PREC_BF16_F32RESID);
+    const bool r16mode = fold || (plain && !fp8 && M >= mmiss_option("ln_fold_min_rows", 6000) && bm_d < 1000);
+    const bool resid16 = r16mode && prune && tw.layers >= 1 &&
+                         (r16opt >= 0 ? r16opt != 0 : e->precision == MMISS_PREC_BF16);
     const int parts = d / 64;
-    if (fuse || fold) {
+    if (fuse || fold || resid16) {  // (separate-LayerNorm mode with a bf16 stream: only the bf16 copy is used)
         MM_PROF("row_stats", st, 3.0 * M * d, (fold ? 6.0 : 4.0) * M * d);
         hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(),
-                           fold ? tw.xb.as<uint16_t>() : nullptr, M, d, parts);
+                           (fold || resid16) ? tw.xb.as<uint16_t>() : nullptr, M, d, parts);
         MM_HIP(hipGetLastError());
     }
     for (int l = 0; l < tw.layers; ++l) {
@@ -341,6 +344,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             g.out = tw.qkv.p; g.ldo = 3 * d; g.M = padded(bm8_qkv); g.N = 3 * d; g.K = d; g.m_valid = M;
             MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_BF16, bm8_qkv, g));
         } else {
+            if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, M, d, eps));
+            else
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
             if (use256(3 * d)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_BF16, tw.h.p, L.wqkv.p, ep, padded(256), 3 * d, d));
@@ -417,6 +422,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             MM_TRY(tap(l + 1));
             continue;
         } else {
+            if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, M, d, eps));
+            else
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
             if (use256(tw.mlp)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_QGELU_BF16, tw.h.p, L.w1.p, ep, padded(256), tw.mlp, d));

@@ -298,3 +298,31 @@ def test_b32_bs256_bf16_residual_stream_and_the_f32_alternative(b32_256):
     print("1 - cos vs oracle, bf16 residual stream: image %.2e text %.2e; f32 stream: image %.2e text %.2e" % (d16 + d32))
     assert max(d16) < 2e-4, d16          # (the bar of the path is COS_TOL = 1e-3; this pins the measured level)
     assert max(d32) < 6e-5, d32          # (text tower: 3.2e-5 with bf16 operands alone)
+
+
+def test_l14_full_depth_bf16_residual_stream_in_the_separate_layernorm_mode():
+    """ViT-L/14 geometry (hidden 1024 > 768: LayerNorm stays a kernel of its own) at 24 images = 6168 token rows, full
+    depth: the large-call default keeps the residual stream in bf16 there too (LayerNorm reads the bf16 rows). Against the
+    fp32 oracle at the 1e-3 bar, next to the f32-stream alternative."""
+    import dataclasses
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.LONGCLIP_L14, t_layers=1, t_vocab=1000, eos_token_id=999)  # vision tower only
+    W = co.init_weights(s, seed=61)
+    rng = np.random.Generator(np.random.Philox(62))
+    px = rng.standard_normal((24, 3, 224, 224), dtype=np.float32)
+    sub = np.array([0, 7, 13, 23])
+    ref = co.embed_images(px[sub], W, s)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=24, max_batch_text=2)
+    enc.load_state_dict(W)
+    out, kern = _kernels_of(lambda: enc.encode_image(px))
+    assert kern.get("gemm_bf16_bias_resid16_k1024", 0) == 23 and kern.get("gemm_bf16_bias_resid16_k4096", 0) == 23, kern
+    assert kern.get("layernorm16", 0) == 47, kern
+    enc.set_precision("bf16-f32resid")
+    out32, kern32 = _kernels_of(lambda: enc.encode_image(px))
+    enc.close()
+    assert "layernorm16" not in kern32 and kern32.get("gemm_bf16_bias_resid_k1024", 0) == 23, kern32
+    d16, d32 = (1 - _cos(out[sub], ref)).max(), (1 - _cos(out32[sub], ref)).max()
+    print("L/14 24 layers, 6168 rows: 1 - cos vs oracle bf16 stream %.2e, f32 stream %.2e" % (d16, d32))
+    assert d16 < 3e-4 and d32 < 3e-5, (d16, d32)   # (bar: COS_TOL = 1e-3; CPU simulation 3-8e-5 / 2-3e-6)

@@ -18,6 +18,8 @@ BT = 64
 t0 = time.perf_counter()
 enc = ClipEncoder(LONGCLIP_L14, device=0, max_batch_image=B, max_batch_text=BT)
 enc.load_state_dict(random_state_dict(LONGCLIP_L14, seed=0))
+if os.environ.get("PRECISION"):   # "bf16-f32resid" = f32 residual stream at every batch size, "fp8"
+    enc.set_precision(os.environ["PRECISION"])
 print({"load_s": round(time.perf_counter() - t0, 1)}, flush=True)
 x = torch.randn(B, 3, 224, 224, device="cuda")
 out = torch.empty(B, 768, device="cuda")
