@@ -463,8 +463,8 @@ def main():
                        "max_1_minus_cos_vs_bf16_path": {"image": cos_img8, "text": cos_txt8},
                        "kernels_image_bs128": k8, "kernels_columns": ["launches", "avg_us", "tflops"],
                        "note": "QKV / FC1 / FC2 on v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3, MX block scales on activations, "
-                               "per-channel scales on weights); out-proj, attention, LayerNorm statistics, residual (f32) "
-                               "and head unchanged; fp8 MFMA peak 5 PF dense"}}
+                               "per-channel scales on weights); out-proj (bf16 operands), attention, LayerNorm statistics and head "
+                               "unchanged; residual stream bf16 as in the bf16 setting at this batch size; fp8 MFMA peak 5 PF dense"}}
         del enc_l, xl, ol
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)

@@ -307,9 +307,9 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // ViT-B/32, 256 images: residual GEMMs 33.8 -> 28.5 us (K = 768), 71.4 -> 66.6 us (K = 3072), encode 3.05 -> 2.91 ms;
     // 1 - cos vs the fp32 oracle 5e-6 -> 5e-5 (tolerance 1e-3).
     const int r16opt = mmiss_option("resid16", -1);
-    const bool r16mode = fold || (plain && !fp8 && M >= mmiss_option("ln_fold_min_rows", 6000) && bm_d < 1000);
+    const bool r16mode = fold || (plain && M >= mmiss_option("ln_fold_min_rows", 6000) && bm_d < 1000);  // (fp8 GEMMs included)
     const bool resid16 = r16mode && prune && tw.layers >= 1 &&
-                         (r16opt >= 0 ? r16opt != 0 : e->precision == MMISS_PREC_BF16);
+                         (r16opt >= 0 ? r16opt != 0 : e->precision != MMISS_PREC_BF16_F32RESID);
     const int parts = d / 64;
     if (fuse || fold || resid16) {  // (separate-LayerNorm mode with a bf16 stream: only the bf16 copy is used)
         MM_PROF("row_stats", st, 3.0 * M * d, (fold ? 6.0 : 4.0) * M * d);
@@ -336,7 +336,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.x.as<float>(), L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
 #endif
         } else if (fp8) {
-            MM_TRY(launch_layernorm_mxfp8(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h8.as<uint8_t>(),
+            MM_TRY(launch_layernorm_mxfp8(st, resid16 ? tw.xb.p : tw.x.p, resid16, L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h8.as<uint8_t>(),
                                           tw.hs.as<uint8_t>(), M, d, eps));
             Gemm8Args g{};
             g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
@@ -406,7 +406,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
 #endif
         } else if (fp8) {
             // LN2 -> MXFP8, FC1 + QuickGELU -> MXFP8 (per row and 64 columns), FC2 + residual: `u` crosses HBM as 1 byte
-            MM_TRY(launch_layernorm_mxfp8(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h8.as<uint8_t>(),
+            MM_TRY(launch_layernorm_mxfp8(st, resid16 ? tw.xb.p : tw.x.p, resid16, L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h8.as<uint8_t>(),
                                           tw.hs.as<uint8_t>(), M, d, eps));
             Gemm8Args g{};
             g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
@@ -417,8 +417,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             g = Gemm8Args{};
             g.A = tw.u8.as<uint8_t>(); g.As = tw.us.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(tw.mlp);
             g.W = L.w2_8.as<uint8_t>(); g.wscale = L.s2.as<float>(); g.bias = L.b2.as<float>();
-            g.out = tw.x.p; g.ldo = d; g.M = padded(bm8_d); g.N = d; g.K = tw.mlp; g.m_valid = M;
-            MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_RESID_F32, bm8_d, g));
+            g.out = resid16 ? tw.xb.p : tw.x.p; g.ldo = d; g.M = padded(bm8_d); g.N = d; g.K = tw.mlp; g.m_valid = M;
+            MM_TRY(launch_gemm8(st, resid16 ? MMISS_EPI8_BIAS_RESID_BF16 : MMISS_EPI8_BIAS_RESID_F32, bm8_d, g));
             MM_TRY(tap(l + 1));
             continue;
         } else {
@@ -1225,7 +1225,7 @@ extern "C" int mmiss_dbg_layernorm_mxfp8(int device, void* hip_stream, const flo
                                          void* out8, void* out_scale, int32_t M, int32_t d, float eps) {
     if (!x || !gamma || !beta || !out8 || !out_scale) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_layernorm_mxfp8: null pointer");
     MM_TRY(mmiss_use_device(device));
-    return launch_layernorm_mxfp8(reinterpret_cast<hipStream_t>(hip_stream), x, gamma, beta, reinterpret_cast<uint8_t*>(out8),
+    return launch_layernorm_mxfp8(reinterpret_cast<hipStream_t>(hip_stream), x, false, gamma, beta, reinterpret_cast<uint8_t*>(out8),
                                   reinterpret_cast<uint8_t*>(out_scale), M, d, eps);
 }
 

@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(8))) int v8i32;
 #define MMISS_EPI8_BIAS_BF16 0        // out bf16 [M,N] = acc * sw[n] + bias[n]                          (QKV)
 #define MMISS_EPI8_QGELU_MXFP8 1      // out e4m3 [M,N] + E8M0 scales = mx(quick_gelu(acc * sw[n] + bias[n]))  (FC1)
 #define MMISS_EPI8_BIAS_RESID_F32 2   // out f32 [M,N] += acc * sw[n] + bias[n]                          (FC2)
+#define MMISS_EPI8_BIAS_RESID_BF16 3  // out bf16 [M,N] = bf16(f32(out) + acc * sw[n] + bias[n])         (FC2, bf16 residual stream)
 
 struct Gemm8Args {
     const uint8_t* A;       // e4m3 [M, K]
@@ -204,6 +205,15 @@ __global__ __launch_bounds__(256, 2) void gemm8_kernel(Gemm8Args g) {
                     resid[j][rh][ch] = *reinterpret_cast<const f32x4*>(
                         reinterpret_cast<const float*>(g.out) + (size_t)(m0 + j * 16 + rh * 8 + rrow) * g.ldo + n0 + ch * 32 + rchunk * 4);
     }
+    u32x4 resid16[EPI == MMISS_EPI8_BIAS_RESID_BF16 ? JT : 1][2];  // 8 consecutive columns of 8 rows per 16-row sub-tile
+    if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16) {
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh)
+                resid16[j][rh] = *reinterpret_cast<const u32x4*>(
+                    reinterpret_cast<const uint16_t*>(g.out) + (size_t)(m0 + j * 16 + rh * 8 + rrow) * g.ldo + n0 + rchunk * 8);
+    }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         if constexpr (EPI == MMISS_EPI8_BIAS_BF16) {
@@ -265,6 +275,23 @@ __global__ __launch_bounds__(256, 2) void gemm8_kernel(Gemm8Args g) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 80 + c16 * 16);
             if (m < g.m_valid)
                 *reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(g.out) + (size_t)m * g.ldo + n0 + c16 * 16) = v;
+        } else if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16) {
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const int row = rh * 8 + rrow, m = m0 + j * 16 + row;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + row * 272 + rchunk * 32);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + row * 272 + rchunk * 32 + 16);
+                const u32x4 old = resid16[j][rh];
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = __uint_as_float(old[e] << 16) + (e < 2 ? lo[2 * e] : hi[2 * e - 4]);
+                    const float b = __uint_as_float(old[e] & 0xFFFF0000u) + (e < 2 ? lo[2 * e + 1] : hi[2 * e - 3]);
+                    pk[e] = pack_bf16x2(a, b);
+                }
+                if (m < g.m_valid)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(g.out) + (size_t)m * g.ldo + n0 + rchunk * 8) = pk;
+            }
         } else {
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
@@ -301,15 +328,16 @@ static int launch_gemm8(hipStream_t st, int epi, int bm, Gemm8Args g) {
     if (epi == MMISS_EPI8_QGELU_MXFP8 && (!g.out_scale || g.ld_os < mx_scale_row_bytes(g.N)))
         MM_FAIL(MMISS_ERR_ARG, "gemm8: the MXFP8 epilogue needs out_scale with >= %d bytes per row", mx_scale_row_bytes(g.N));
     if (g.m_fast == 0 && g.N / 128 >= 8) g.m_fast = mmiss_option("gemm_band", 5);  // banded tile order, as gemm_bf16.h
-    static const char* names[] = {"gemm_fp8_bias", "gemm_fp8_qgelu_mx", "gemm_fp8_bias_resid"};
-    if (epi < 0 || epi > 2) MM_FAIL(MMISS_ERR_ARG, "gemm8: bad epilogue %d", epi);
+    static const char* names[] = {"gemm_fp8_bias", "gemm_fp8_qgelu_mx", "gemm_fp8_bias_resid", "gemm_fp8_bias_resid16"};
+    if (epi < 0 || epi > 3) MM_FAIL(MMISS_ERR_ARG, "gemm8: bad epilogue %d", epi);
     const int mv = g.m_valid < g.M ? g.m_valid : g.M;
-    const double out_b = epi == MMISS_EPI8_BIAS_BF16 ? 2.0 : (epi == MMISS_EPI8_QGELU_MXFP8 ? 1.0 : 8.0);
+    const double out_b = epi == MMISS_EPI8_BIAS_BF16 ? 2.0 : (epi == MMISS_EPI8_QGELU_MXFP8 ? 1.0 : (epi == MMISS_EPI8_BIAS_RESID_BF16 ? 4.0 : 8.0));
     MM_PROF(names[epi], st, 2.0 * mv * (double)g.N * g.K, (double)mv * g.K + (double)g.N * g.K + out_b * mv * g.N);
 #define GEMM8_CASE(BMV)                                                                                    \
     case BMV:                                                                                              \
         if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm8_inst<BMV, MMISS_EPI8_BIAS_BF16>(st, g);       \
         if (epi == MMISS_EPI8_QGELU_MXFP8) return launch_gemm8_inst<BMV, MMISS_EPI8_QGELU_MXFP8>(st, g);   \
+        if (epi == MMISS_EPI8_BIAS_RESID_BF16) return launch_gemm8_inst<BMV, MMISS_EPI8_BIAS_RESID_BF16>(st, g); \
         return launch_gemm8_inst<BMV, MMISS_EPI8_BIAS_RESID_F32>(st, g);
     switch (bm) {
         GEMM8_CASE(128)
@@ -356,20 +384,28 @@ __global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const uint16_
 // (encoder_kernels.h; HF:modeling_clip.py:358-360), the normalised row quantised per 32 columns. One wave per row held in
 // registers: lane l holds columns (i*64 + l)*4 .. +3, so 8 consecutive lanes hold one 32-column block.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <bool IN_BF16>  // IN_BF16: x is a bf16 residual stream (widened exactly)
+__global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, uint8_t* __restrict__ out,
                                                               uint8_t* __restrict__ out_scale, int M, int d, int ld_os,
                                                               float eps) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
-    const float* xr = x + (size_t)r * d;
     f32x4 v[4];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (i * 64 + lane) * 4;
-        v[i] = (c < d) ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (IN_BF16) {
+            u32x2 w = u32x2{0u, 0u};
+            if (c < d) w = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(x) + (size_t)r * d + c);
+            v[i] = f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16),
+                         __uint_as_float(w[1] & 0xFFFF0000u)};
+        } else {
+            v[i] = (c < d) ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + (size_t)r * d + c)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)d;
@@ -411,12 +447,16 @@ __global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const float* __res
     }
 }
 
-static int launch_layernorm_mxfp8(hipStream_t st, const float* x, const float* gamma, const float* beta, uint8_t* out,
+static int launch_layernorm_mxfp8(hipStream_t st, const void* x, bool x_bf16, const float* gamma, const float* beta, uint8_t* out,
                                   uint8_t* out_scale, int M, int d, float eps) {
     if (d > 1024 || (d % 32)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "layernorm_mxfp8: d=%d (need d <= 1024, d %% 32 == 0)", d);
-    MM_PROF("layernorm_mxfp8", st, 8.0 * M * d, (double)M * d * 5);
-    hipLaunchKernelGGL(layernorm_mxfp8_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, beta, out, out_scale, M, d,
-                       mx_scale_row_bytes(d), eps);
+    MM_PROF(x_bf16 ? "layernorm16_mxfp8" : "layernorm_mxfp8", st, 8.0 * M * d, (double)M * d * (x_bf16 ? 3 : 5));
+    if (x_bf16)
+        hipLaunchKernelGGL(layernorm_mxfp8_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, beta, out, out_scale, M, d,
+                           mx_scale_row_bytes(d), eps);
+    else
+        hipLaunchKernelGGL(layernorm_mxfp8_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, beta, out, out_scale, M, d,
+                           mx_scale_row_bytes(d), eps);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }

@@ -321,8 +321,15 @@ def test_l14_full_depth_bf16_residual_stream_in_the_separate_layernorm_mode():
     assert kern.get("layernorm16", 0) == 47, kern
     enc.set_precision("bf16-f32resid")
     out32, kern32 = _kernels_of(lambda: enc.encode_image(px))
-    enc.close()
     assert "layernorm16" not in kern32 and kern32.get("gemm_bf16_bias_resid_k1024", 0) == 23, kern32
-    d16, d32 = (1 - _cos(out[sub], ref)).max(), (1 - _cos(out32[sub], ref)).max()
-    print("L/14 24 layers, 6168 rows: 1 - cos vs oracle bf16 stream %.2e, f32 stream %.2e" % (d16, d32))
+    # fp8 GEMMs (QKV / FC1 / FC2) on the same bf16 stream: its own, wider bar (tests/test_fp8_gpu.py)
+    enc.set_precision("fp8")
+    out8, kern8 = _kernels_of(lambda: enc.encode_image(px))
+    enc.close()
+    assert kern8.get("gemm_fp8_bias_resid16", 0) == 23 and kern8.get("layernorm16_mxfp8", 0) == 47, kern8
+    assert kern8.get("gemm_bf16_bias_resid16_k1024", 0) == 23, kern8
+    d16, d32, d8 = ((1 - _cos(o[sub], ref)).max() for o in (out, out32, out8))
+    print("L/14 24 layers, 6168 rows: 1 - cos vs oracle bf16 stream %.2e, f32 stream %.2e, fp8 GEMMs on the bf16 stream %.2e"
+          % (d16, d32, d8))
     assert d16 < 3e-4 and d32 < 3e-5, (d16, d32)   # (bar: COS_TOL = 1e-3; CPU simulation 3-8e-5 / 2-3e-6)
+    assert d8 < 5e-3, d8
