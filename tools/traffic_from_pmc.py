@@ -27,7 +27,7 @@ CLASSES = {
     "score_gemm_f16": r"gemm256_kernelIDF16_Li5E",
     "scan_topk_f16": r"scan_topk_kernelIDF16_",
     "layernorm": r"layernorm_kernel<true>",
-    "attention": r"attention_kernel<",
+    "attention": r"attention(_heads)?_kernel<",
     "im2col": r"im2col_kernel<",
 }
 ALGORITHMIC = {  # bytes per launch the kernel must move, averaged over the shapes in the class
@@ -54,8 +54,9 @@ def main(fetch_csv, write_csv, out):
     fetch, write = per_kernel(fetch_csv), per_kernel(write_csv)
     res = {"_note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes, "
                     "--kernel-trace only), FETCH_SIZE doubled as MI355X_MICROARCH.md 'HBM' prescribes for gfx950; command: "
-                    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 3 --warmup 2 "
-                    "--no-cpu-baseline --no-kernel-events --no-text; aggregated by tools/traffic_from_pmc.py"}
+                    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 5 --warmup 2 "
+                    "--retrieval-rows 0 --no-cpu-baseline --no-kernel-events --no-text (tools/profile_pmc.sh); Infinity-Cache "
+                    "hits are counted: fabric traffic, an upper bound on HBM traffic; aggregated by tools/traffic_from_pmc.py"}
     for cls, pat in CLASSES.items():
         rx = re.compile(pat)
         fv = [v for k, vs in fetch.items() if rx.search(k) for v in vs]
@@ -68,6 +69,7 @@ def main(fetch_csv, write_csv, out):
                "write_bytes": round(wb), "traffic_bytes": round(fb + wb)}
         if cls in ALGORITHMIC:
             ent["algorithmic_bytes_avg"] = ALGORITHMIC[cls]
+            ent["ratio_to_algorithmic"] = round((fb + wb) / ALGORITHMIC[cls], 3)
         res[cls] = ent
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
