@@ -609,22 +609,57 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
     for (int i = tid; i < npow; i += nthreads) { sd[i] = INFINITY; sr[i] = INT32_MAX; }
     __syncthreads();
-    for (int c = wave; c < a.ncand; c += nwaves) {
-        int64_t row;
-        if (a.group_mode) {
-            const int g = a.cand[(size_t)b * a.cand_stride + (c >> 4)];
-            if (g < 0) continue;  // wave-uniform
-            row = groupmax_row(g, c & 15);
-            if (row >= a.nrows) continue;
-        } else {
-            row = a.cand[(size_t)b * a.cand_stride + c];
-            if (row < 0) continue;  // wave-uniform
+    // Canonical dot products, FOUR candidate rows per wave at a time: the 16 lanes p of a quarter wave stand for the 64
+    // lanes of the canonical reduction, lane p holding the partial sums of canonical lanes 4p .. 4p+3 (elements
+    // d = 4p + j + 64 i, i ascending — the same additions in the same order). The butterfly's stages xor 32, 16, 8, 4 pair
+    // canonical lanes 4p + j and 4(p ^ {8,4,2,1}) + j: a shuffle inside the quarter wave per partial sum; stages xor 2, 1
+    // pair partial sums of one lane. Same bits as one row per wave (canon_dot in oracle/), a quarter of the dependent
+    // steps, 8- / 16-byte row loads instead of 2- / 4-byte ones, and the query slice read once per four rows.
+    const int p16 = lane & 15, sub = lane >> 4;
+    for (int c0 = wave * 4; c0 < a.ncand; c0 += nwaves * 4) {
+        const int c = c0 + sub;
+        int64_t row = -1;
+        if (c < a.ncand) {
+            if (a.group_mode) {
+                const int g = a.cand[(size_t)b * a.cand_stride + (c >> 4)];
+                if (g >= 0) {
+                    row = groupmax_row(g, c & 15);
+                    if (row >= a.nrows) row = -1;
+                }
+            } else {
+                row = a.cand[(size_t)b * a.cand_stride + c];
+            }
         }
-        const T* rv = reinterpret_cast<const T*>(a.rows) + (size_t)row * a.D;
-        double acc = 0.0;
-        for (int d = lane; d < a.D; d += 64) acc = acc + (double)qv[d] * widen<T>(rv[d]);
-        const double dot = wave_butterfly_sum(acc);
-        if (lane == 0) {
+        const bool live = row >= 0;  // (no candidate, or an empty index: nothing is dereferenced)
+        const T* rv = reinterpret_cast<const T*>(a.rows) + (size_t)(live ? row : 0) * a.D + 4 * p16;
+        const float* qp = qv + 4 * p16;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int d0 = 0; d0 < a.D; d0 += 64) {
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + d0);
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (sizeof(T) == 2) {
+                u32x2 w = u32x2{0u, 0u};
+                if (live) w = *reinterpret_cast<const u32x2*>(rv + d0);
+                const _Float16* h = reinterpret_cast<const _Float16*>(&w);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rr[j] = (float)h[j];
+            } else {
+                f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live) w = *reinterpret_cast<const f32x4*>(rv + d0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rr[j] = w[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (double)qq[j] * (double)rr[j];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __shfl_xor(acc[j], o);
+        }
+        const double t0 = acc[0] + acc[2], t1 = acc[1] + acc[3];
+        const double dot = t0 + t1;
+        if (p16 == 0 && row >= 0) {
             sd[c] = (float)(1.0 - dot);
             sr[c] = (int32_t)row;
         }
