@@ -90,26 +90,41 @@ __device__ __forceinline__ bool cand_better(float sa, int ra, float sb, int rb) 
     return sa > sb || (sa == sb && ra < rb);
 }
 
+// lane ^ J exchange of one dword. J = 1, 2, 4, 8 stay inside a row of 16 lanes: DPP moves in the VALU (quad_perm for 1 and
+// 2; lane ^ 4 = half-mirror then quad reverse, lane ^ 8 = row mirror then half-mirror) instead of ds_bpermute round trips
+// through the LDS crossbar — 18 of the 21 stages of the 64-lane sort; 16 and 32 keep the bpermute.
+template <int J>
+__device__ __forceinline__ int lane_xor(int v) {
+    if constexpr (J == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    else if constexpr (J == 4)
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, false), 0x1B, 0xF, 0xF, false);
+    else if constexpr (J == 8)
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, false), 0x141, 0xF, 0xF, false);
+    else return __shfl_xor(v, J);
+}
+
 // sorts the 64 (s, r) pairs held one per lane: best first (bitonic network, 21 compare-exchange stages)
-__device__ __forceinline__ void wave_sort64_stage(float& s, int& r, int lane, int k, int j) {
-    const float os = __shfl_xor(s, j);
-    const int orr = __shfl_xor(r, j);
-    const bool lower = (lane & j) == 0;
-    const bool up = (lane & k) == 0;  // at k == 64 every lane is "up": final order best-first
+template <int K, int J>
+__device__ __forceinline__ void wave_sort64_stage(float& s, int& r, int lane) {
+    const float os = __int_as_float(lane_xor<J>(__float_as_int(s)));
+    const int orr = lane_xor<J>(r);
+    const bool lower = (lane & J) == 0;
+    const bool up = (lane & K) == 0;  // at K == 64 every lane is "up": final order best-first
     const bool keep_best = (lower == up);
     const bool take = keep_best ? cand_better(os, orr, s, r) : cand_better(s, r, os, orr);
     if (take) { s = os; r = orr; }
 }
 __device__ __forceinline__ void wave_sort64(float& s, int& r, int lane) {
-    wave_sort64_stage(s, r, lane, 2, 1);
-    wave_sort64_stage(s, r, lane, 4, 2);  wave_sort64_stage(s, r, lane, 4, 1);
-    wave_sort64_stage(s, r, lane, 8, 4);  wave_sort64_stage(s, r, lane, 8, 2);  wave_sort64_stage(s, r, lane, 8, 1);
-    wave_sort64_stage(s, r, lane, 16, 8); wave_sort64_stage(s, r, lane, 16, 4); wave_sort64_stage(s, r, lane, 16, 2);
-    wave_sort64_stage(s, r, lane, 16, 1);
-    wave_sort64_stage(s, r, lane, 32, 16); wave_sort64_stage(s, r, lane, 32, 8); wave_sort64_stage(s, r, lane, 32, 4);
-    wave_sort64_stage(s, r, lane, 32, 2);  wave_sort64_stage(s, r, lane, 32, 1);
-    wave_sort64_stage(s, r, lane, 64, 32); wave_sort64_stage(s, r, lane, 64, 16); wave_sort64_stage(s, r, lane, 64, 8);
-    wave_sort64_stage(s, r, lane, 64, 4);  wave_sort64_stage(s, r, lane, 64, 2);  wave_sort64_stage(s, r, lane, 64, 1);
+    wave_sort64_stage<2, 1>(s, r, lane);
+    wave_sort64_stage<4, 2>(s, r, lane);  wave_sort64_stage<4, 1>(s, r, lane);
+    wave_sort64_stage<8, 4>(s, r, lane);  wave_sort64_stage<8, 2>(s, r, lane);  wave_sort64_stage<8, 1>(s, r, lane);
+    wave_sort64_stage<16, 8>(s, r, lane); wave_sort64_stage<16, 4>(s, r, lane); wave_sort64_stage<16, 2>(s, r, lane);
+    wave_sort64_stage<16, 1>(s, r, lane);
+    wave_sort64_stage<32, 16>(s, r, lane); wave_sort64_stage<32, 8>(s, r, lane); wave_sort64_stage<32, 4>(s, r, lane);
+    wave_sort64_stage<32, 2>(s, r, lane);  wave_sort64_stage<32, 1>(s, r, lane);
+    wave_sort64_stage<64, 32>(s, r, lane); wave_sort64_stage<64, 16>(s, r, lane); wave_sort64_stage<64, 8>(s, r, lane);
+    wave_sort64_stage<64, 4>(s, r, lane);  wave_sort64_stage<64, 2>(s, r, lane);  wave_sort64_stage<64, 1>(s, r, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,8 +360,9 @@ struct SelectArgs {
 __device__ __forceinline__ void lane_list_insert(float& ls, int& lr, float xs, int xr, int lane) {
     const unsigned long long better = __ballot(ls > xs || (ls == xs && lr < xr));
     const int p = __popcll(better);  // the list is sorted best-first, so the better entries are lanes [0, p)
-    const float us = __shfl_up(ls, 1);
-    const int ur = __shfl_up(lr, 1);
+    // lane i <- lane i-1 across the whole wave: DPP wave_shr:1 (gfx9 family), lane 0 keeps its own value (unused: p >= 0)
+    const float us = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ls), __float_as_int(ls), 0x138, 0xF, 0xF, false));
+    const int ur = __builtin_amdgcn_update_dpp(lr, lr, 0x138, 0xF, 0xF, false);
     if (lane > p) { ls = us; lr = ur; }
     else if (lane == p) { ls = xs; lr = xr; }
 }
@@ -371,9 +387,10 @@ __global__ __launch_bounds__(256) void select_topk_kernel(SelectArgs a) {
     int tau_r = SCAN_ROW_NONE;
     // wave w takes columns c_begin + 256*w + 4*lane .. +3 (one 16-byte load per lane, 1 KiB per wave), stepping 1024;
     // c_begin and ldg are multiples of 4, so the loads are aligned
-    for (int c0 = c_begin + wave * 256; c0 < c_end; c0 += 1024) {
+    auto fetch = [&](int c0) {
         const int c = c0 + lane * 4;
         f32x4 v = {SCAN_NEG_INF, SCAN_NEG_INF, SCAN_NEG_INF, SCAN_NEG_INF};
+        if (c0 >= c_end) return v;
         if (c + 3 < c_end) {
             v = *reinterpret_cast<const f32x4*>(row + c);
         } else {
@@ -381,6 +398,13 @@ __global__ __launch_bounds__(256) void select_topk_kernel(SelectArgs a) {
             for (int e = 0; e < 4; ++e)
                 if (c + e < c_end) v[e] = row[c + e];
         }
+        return v;
+    };
+    f32x4 vnext = fetch(c_begin + wave * 256);
+    for (int c0 = c_begin + wave * 256; c0 < c_end; c0 += 1024) {
+        const int c = c0 + lane * 4;
+        const f32x4 v = vnext;
+        vnext = fetch(c0 + 1024);  // the next step's values fly while this step's are filed
         // The wave's first 64 values SEED the list through one bitonic sort (same list as 64 inserts one by one: the order
         // is total). With ~400 values per wave (6250 groups per query at 100k rows, 16 waves per query) the one-by-one
         // start-up was a quarter of the kernel: 39.9 -> 31.3 us at Q = 256. (Seeding with all 256 first values — four sorts
@@ -533,6 +557,7 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(MergeArgs a) {
         wave_sort64(s, r, lane);
         for (int w = 1; w < 4; ++w) {
             const int cw = cnt[w];
+            if (cw == 0) continue;  // (wave-uniform; a short input leaves the later waves' lists empty)
             if (lane >= kp) { s = SCAN_NEG_INF; r = SCAN_ROW_NONE; }
             if (lane >= 32 && lane - 32 < cw) { s = cs[w][lane - 32]; r = cr[w][lane - 32]; }
             wave_sort64(s, r, lane);
