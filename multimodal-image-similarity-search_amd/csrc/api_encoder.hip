@@ -228,7 +228,7 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     MM_TRY(alloc_zero(tw.hc, (size_t)Bp * d * 2));
     MM_TRY(alloc_zero(tw.ctxc, (size_t)Bp * d * 2));
     MM_TRY(alloc_zero(tw.uc, (size_t)Bp * tw.mlp * 2));
-    MM_TRY(alloc_zero(tw.stats, (size_t)Mp * (d / 64) * 2 * 4));
+    MM_TRY(alloc_zero(tw.stats, (size_t)Mp * (d / 16) * 2 * 4));  // (one partial per 64 columns; per 16 in the skinny folded mode)
     MM_TRY(alloc_zero(tw.xb, (size_t)Mp * d * 2));
     if (e->precision == MMISS_PREC_FP8) {
         MM_TRY(alloc_zero(tw.h8, (size_t)Mp * d));
@@ -310,7 +310,24 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     const bool r16mode = fold || (plain && M >= mmiss_option("ln_fold_min_rows", 6000) && bm_d < 1000);  // (fp8 GEMMs included)
     const bool resid16 = r16mode && prune && tw.layers >= 1 &&
                          (r16opt >= 0 ? r16opt != 0 : e->precision != MMISS_PREC_BF16_F32RESID);
+    // One request at a time (all four GEMMs of a layer on the weight-streaming skinny kernel, M <= 128): LayerNorm folded
+    // into the QKV / FC1 weights there as well — the skinny residual GEMMs leave a bf16 copy of the new rows and their
+    // partial statistics per 16 columns, the skinny QKV / FC1 GEMMs apply (mean, rstd) in their epilogue. 24 of the ~99
+    // launches of a ViT-B/32 request disappear. Option skinny_fold = 0 keeps the LayerNorm kernels.
+    bool sfold = false;
+    if (plain && !fp8 && M <= 128 && (d % 128) == 0 && mmiss_option("skinny_fold", 1) != 0) {
+        GemmEpi probe{};
+        probe.stats16 = 1;
+        sfold = gemm_skinny_ok(MMISS_EPI_LNFOLD_BF16, M, 3 * d, d, probe) && gemm_skinny_ok(MMISS_EPI_LNFOLD_QGELU_BF16, M, tw.mlp, d, probe) &&
+                gemm_skinny_ok(MMISS_EPI_BIAS_RESID_F32, M, d, d, probe) && gemm_skinny_ok(MMISS_EPI_BIAS_RESID_F32, M, d, tw.mlp, probe);
+    }
     const int parts = d / 64;
+    if (sfold) {
+        MM_PROF("row_stats", st, 3.0 * M * d, 6.0 * M * d);
+        hipLaunchKernelGGL(skinny_row_stats16_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(),
+                           tw.xb.as<uint16_t>(), M, d);
+        MM_HIP(hipGetLastError());
+    }
     if (fuse || fold || resid16) {  // (separate-LayerNorm mode with a bf16 stream: only the bf16 copy is used)
         MM_PROF("row_stats", st, 3.0 * M * d, (fold ? 6.0 : 4.0) * M * d);
         hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(),
@@ -343,6 +360,10 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             g.W = L.wqkv8.as<uint8_t>(); g.wscale = L.sqkv.as<float>(); g.bias = L.bqkv.as<float>();
             g.out = tw.qkv.p; g.ldo = 3 * d; g.M = padded(bm8_qkv); g.N = 3 * d; g.K = d; g.m_valid = M;
             MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_BF16, bm8_qkv, g));
+        } else if (sfold) {
+            ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
+            ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = d / 16; ep.ln_eps = eps; ep.stats16 = 1;
+            MM_TRY(launch_gemm_skinny_fold(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, M, 3 * d, d));
         } else {
             if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, M, d, eps));
             else
@@ -380,8 +401,9 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = M;
-        ep.stats_out = (fuse || fold) ? tw.stats.as<float>() : nullptr;  // row statistics of the new residual for LN2
-        ep.xb_out = fold ? tw.xb.p : nullptr;
+        ep.stats_out = (fuse || fold || sfold) ? tw.stats.as<float>() : nullptr;  // row statistics of the new residual for LN2
+        ep.xb_out = (fold || sfold) ? tw.xb.p : nullptr;
+        ep.stats16 = sfold ? 1 : 0;
         if (resid16) {  // the bf16 rows ARE the residual stream: read-modify-write in place, no f32 stream
             ep.out = tw.xb.p; ep.xb_out = nullptr;
             MM_TRY(launch_gemm_resid16(st, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
@@ -421,6 +443,10 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             MM_TRY(launch_gemm8(st, resid16 ? MMISS_EPI8_BIAS_RESID_BF16 : MMISS_EPI8_BIAS_RESID_F32, bm8_d, g));
             MM_TRY(tap(l + 1));
             continue;
+        } else if (sfold) {
+            ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
+            ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = d / 16; ep.ln_eps = eps; ep.stats16 = 1;
+            MM_TRY(launch_gemm_skinny_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, M, tw.mlp, d));
         } else {
             if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, M, d, eps));
             else
@@ -431,8 +457,9 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         }
         ep = GemmEpi{};
         ep.out = tw.x.p; ep.bias = L.b2.as<float>(); ep.ldo = d; ep.m_valid = M;
-        ep.stats_out = (fuse || fold) ? tw.stats.as<float>() : nullptr;  // ... and for the next layer's LN1
-        ep.xb_out = fold ? tw.xb.p : nullptr;
+        ep.stats_out = (fuse || fold || sfold) ? tw.stats.as<float>() : nullptr;  // ... and for the next layer's LN1
+        ep.xb_out = (fold || sfold) ? tw.xb.p : nullptr;
+        ep.stats16 = sfold ? 1 : 0;
         ep.splitk_ws = tw.splitk.as<float>(); ep.splitk_ws_bytes = tw.splitk.bytes;
         if (resid16) {
             ep.out = tw.xb.p; ep.xb_out = nullptr;

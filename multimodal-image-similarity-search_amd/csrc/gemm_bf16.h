@@ -37,6 +37,7 @@ struct GemmEpi {
     // BIAS_RESID_F32: if set, partial (sum, sumsq) of the NEW residual rows, [M][N/64][2] — the next LayerNorm's input
     float* stats_out;
     void* xb_out;           // BIAS_RESID_F32: if set, bf16 copy of the new residual rows [M, ldo] (next GEMM's A operand)
+    int stats16;            // skinny kernels (gemm_skinny.h): stats_out / ln_stats hold one partial per SIXTEEN columns
     // split-K (launch_gemm only): f32 scratch for the partial products [splits][M][N]; null = never split
     float* splitk_ws;
     size_t splitk_ws_bytes;

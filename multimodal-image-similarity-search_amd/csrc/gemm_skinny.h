@@ -41,6 +41,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // folded LayerNorm: (mean, rstd) of the row this lane finishes first (m-tile t = wave), summed from its K/16 partial sums
+    // right behind the first trip's operand loads, so that these loads fly under the K loop's own load latency
+    constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
+    auto row_mean_rstd = [&](int m, float& mean, float& rstd) {
+        const f32x4* st = reinterpret_cast<const f32x4*>(ep.ln_stats + (size_t)m * ep.ln_parts * 2);
+        float s1 = 0.f, s2 = 0.f;
+        const int n4 = ep.ln_parts >> 1;
+        for (int q0 = 0; q0 < n4; q0 += 8) {  // eight loads in flight per step (K = 768: three steps, not 24 round trips)
+            f32x4 buf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) buf[j] = (q0 + j < n4) ? st[q0 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1 += buf[j][0] + buf[j][2]; s2 += buf[j][1] + buf[j][3]; }
+        }
+        const float kd = (float)(ep.ln_parts * 16);
+        mean = s1 / kd;
+        rstd = 1.0f / sqrtf(fmaxf(s2 / kd - mean * mean, 0.f) + ep.ln_eps);
+    };
+    float pre_mean = 0.f, pre_rstd = 1.f;
+
     // U k-steps per trip: every load of the trip (U weight fragments from HBM/MALL, U*MT activation fragments from L2)
     // is issued before its first MFMA - the loop is bound by memory latency, so what matters is loads in flight.
     // The launcher picks NW so that a wave's whole K-slice is one trip where registers allow (U*(1+MT)*4 VGPRs).
@@ -52,6 +72,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
                 w[u] = *reinterpret_cast<const bf16x8*>(wp + k + 32 * u);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const bf16x8*>(ab + aoff[t] + k + 32 * u);
+            }
+        }
+        if constexpr (FOLD) {  // behind the first trip's operand loads: both latencies run together
+            if (k == 0) {
+                const int m = m_base + wave * 16 + fr;
+                if (wave < MT && m < M) row_mean_rstd(m, pre_mean, pre_rstd);
             }
         }
 #pragma unroll
@@ -74,6 +100,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[(w * MT + t) * 64 + lane];
         const int m = m_base + t * 16 + fr;
+        if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+            if (ep.stats_out) {
+                // partial (sum, sumsq) of the NEW residual row over this workgroup's 16 columns: the four lanes fr + 16 fg of
+                // a row, fixed xor order, one writer -> deterministic. [M][N/16][2]: the next folded skinny GEMM sums them.
+                float rs = 0.f, rq = 0.f;
+                if (m < M) {
+                    const f32x4 nv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.out) + (size_t)m * ep.ldo + n) +
+                                     v + *reinterpret_cast<const f32x4*>(ep.bias + n);
+                    rs = (nv[0] + nv[1]) + (nv[2] + nv[3]);
+                    rq = (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
+                }
+                rs += __shfl_xor(rs, 16); rq += __shfl_xor(rq, 16);
+                rs += __shfl_xor(rs, 32); rq += __shfl_xor(rq, 32);
+                if (fg == 0 && m < M) {
+                    float* so = ep.stats_out + ((size_t)m * (N >> 4) + (n0 >> 4)) * 2;
+                    so[0] = rs;
+                    so[1] = rq;
+                }
+            }
+        }
         if (m >= M) continue;
         if constexpr (EPI == MMISS_EPI_F32) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n) = v;
@@ -89,10 +135,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
             pk[0] = pack_bf16x2(y[0], y[1]);
             pk[1] = pack_bf16x2(y[2], y[3]);
             *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n) = pk;
+        } else if constexpr (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16) {
+            // LayerNorm folded into the weights (gemm_bf16.h, epilogues 7 / 8): A = bf16(x), W = bf16(W * gamma),
+            // y = rstd_m * (acc - mean_m * c_n) + b'_n; (mean, rstd) of row m from the 16-column partial sums the producing
+            // skinny residual GEMM (or skinny_row_stats16_kernel) left in ep.ln_stats [M][ln_parts][2], ln_parts = K / 16
+            float mean = pre_mean, rstd = pre_rstd;
+            if (t != wave) row_mean_rstd(m, mean, rstd);  // (more m-tiles than waves: the later ones pay the loads here)
+            const f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + n);
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(ep.aux + n);
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y[r] = rstd * (v[r] - mean * cv[r]) + b[r];
+                if constexpr (EPI == MMISS_EPI_LNFOLD_QGELU_BF16) y[r] = quick_gelu(y[r]);
+            }
+            u32x2 pk;
+            pk[0] = pack_bf16x2(y[0], y[1]);
+            pk[1] = pack_bf16x2(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n) = pk;
         } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
             v += *reinterpret_cast<const f32x4*>(ep.bias + n);
             float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
-            *reinterpret_cast<f32x4*>(p) = *reinterpret_cast<const f32x4*>(p) + v;
+            v = *reinterpret_cast<const f32x4*>(p) + v;
+            *reinterpret_cast<f32x4*>(p) = v;
+            if (ep.xb_out) {  // bf16 copy of the new residual rows: the A operand of the next folded GEMM
+                u32x2 pk;
+                pk[0] = pack_bf16x2(v[0], v[1]);
+                pk[1] = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(ep.xb_out) + (size_t)m * ep.ldo + n) = pk;
+            }
         } else {  // MMISS_EPI_PATCH_F32
             const int img = m / ep.p0, pt = m - img * ep.p0;
             const f32x4 pos = *reinterpret_cast<const f32x4*>(ep.aux + (size_t)(1 + pt) * ep.ldo + n);
@@ -110,8 +181,9 @@ static inline bool gemm_skinny_ok(int epi, int mv, int N, int K, const GemmEpi& 
     if (mmiss_option("gemm_skinny", 1) == 0) return false;
     const int forced = mmiss_option("gemm_skinny_max_m", 0);
     const int max_m = forced > 0 ? forced : (N <= 1024 ? 320 : 128);
-    return mv >= 1 && mv <= max_m && (N % 16) == 0 && (K % 128) == 0 && epi >= 0 && epi <= 4 && !ep.stats_out &&
-           !ep.xb_out;
+    const bool fold = epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16;  // (launch_gemm_skinny_fold only)
+    if ((ep.stats_out || ep.xb_out || fold) && !ep.stats16) return false;  // the tiled kernels' 64-column statistics layout
+    return mv >= 1 && mv <= max_m && (N % 16) == 0 && (K % 128) == 0 && ((epi >= 0 && epi <= 4) || fold);
 }
 
 template <int EPI, int MT, int NW>
@@ -171,6 +243,44 @@ static int launch_gemm_skinny(hipStream_t st, int epi, const void* A, const void
         case MMISS_EPI_BIAS_BF16: return launch_gemm_skinny_mt<MMISS_EPI_BIAS_BF16>(st, A, W, ep, mv, N, K);
         case MMISS_EPI_BIAS_QGELU_BF16: return launch_gemm_skinny_mt<MMISS_EPI_BIAS_QGELU_BF16>(st, A, W, ep, mv, N, K);
         case MMISS_EPI_BIAS_RESID_F32: return launch_gemm_skinny_mt<MMISS_EPI_BIAS_RESID_F32>(st, A, W, ep, mv, N, K);
+        case MMISS_EPI_LNFOLD_BF16: return launch_gemm_skinny_mt<MMISS_EPI_LNFOLD_BF16>(st, A, W, ep, mv, N, K);
+        case MMISS_EPI_LNFOLD_QGELU_BF16: return launch_gemm_skinny_mt<MMISS_EPI_LNFOLD_QGELU_BF16>(st, A, W, ep, mv, N, K);
         default: return launch_gemm_skinny_mt<MMISS_EPI_PATCH_F32>(st, A, W, ep, mv, N, K);
+    }
+}
+
+// Folded-LayerNorm GEMM on the skinny kernel (one request at a time: the LayerNorm launches disappear): A = bf16(x) rows,
+// W = gamma-folded weights, ep.aux = c, ep.bias = b', ep.ln_stats = [M][K/16][2] partial sums, ep.ln_parts = K / 16.
+static int launch_gemm_skinny_fold(hipStream_t st, int epi, const void* A, const void* W, const GemmEpi& ep, int mv, int N, int K) {
+    if (!ep.stats16 || !ep.ln_stats || !ep.aux || !ep.bias || ep.ln_parts * 16 != K || (ep.ln_parts & 1) ||
+        !gemm_skinny_ok(epi, mv, N, K, ep))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm_skinny_fold: M=%d N=%d K=%d parts=%d", mv, N, K, ep.ln_parts);
+    MM_PROF(epi == MMISS_EPI_LNFOLD_BF16 ? "gemm_skinny_lnfold_bias" : "gemm_skinny_lnfold_qgelu", st, gemm_flops(mv, N, K),
+            2.0 * ((double)mv * K + (double)N * K) + 2.0 * mv * N);
+    return launch_gemm_skinny(st, epi, A, W, ep, mv, N, K);
+}
+
+// (sum, sumsq) of every 16-column slice of the residual rows + their bf16 copy: the entry point of the skinny folded mode
+// (afterwards the skinny residual GEMMs' epilogues keep both up to date). One wave per row.
+static __global__ __launch_bounds__(256) void skinny_row_stats16_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                                uint16_t* __restrict__ xb, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    for (int c = lane * 4; c < d; c += 256) {   // 4 lanes share a 16-column slice
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * d + c);
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(xb + (size_t)r * d + c) = pk;
+        float s = (v[0] + v[1]) + (v[2] + v[3]);
+        float q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+        s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+        if ((lane & 3) == 0) {
+            float* o = stats + ((size_t)r * (d >> 4) + (c >> 4)) * 2;
+            o[0] = s;
+            o[1] = q;
+        }
     }
 }

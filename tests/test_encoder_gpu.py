@@ -70,9 +70,19 @@ def test_last_layer_pruning_matches_full_computation(tiny):
     rng = np.random.Generator(np.random.Philox(77))
     px = rng.standard_normal((7, 3, s.v_image, s.v_image), dtype=np.float32)
     ids = co.synthetic_text_ids(7, s.t_ctx, s.t_vocab, s.eos_token_id, seed=78)
-    np.testing.assert_allclose(pruned.encode_image(px), enc.encode_image(px), atol=1e-6)
-    np.testing.assert_allclose(pruned.encode_text(ids), enc.encode_text(ids), atol=1e-6)
     from mmiss_amd import _lib
+
+    # identical arithmetic on both sides (separate LayerNorm kernels): the pruned tail must reproduce the full computation
+    _lib.set_option("skinny_fold", 0)
+    try:
+        np.testing.assert_allclose(pruned.encode_image(px), enc.encode_image(px), atol=1e-6)
+        np.testing.assert_allclose(pruned.encode_text(ids), enc.encode_text(ids), atol=1e-6)
+    finally:
+        _lib.set_option("skinny_fold", 1)
+    # default at this size: LayerNorm folded into the skinny GEMMs; the pruned tail still runs its B rows through a LayerNorm
+    # kernel (bf16(LN(x)) W vs the folded bf16(x) (W gamma) form): two bf16 roundings of the same function
+    assert (1 - _cos(pruned.encode_image(px), enc.encode_image(px))).max() < 1e-4
+    assert (1 - _cos(pruned.encode_text(ids), enc.encode_text(ids))).max() < 1e-4
 
     for mode in ((1, 2) if _lib.has_experiments() else (2,)):  # the pruned tail is the same whatever the LayerNorm mode
         pruned.set_fuse_ln(mode)
@@ -340,3 +350,46 @@ def test_text_padding_is_trimmed_without_changing_results(tiny):
     b = enc.encode_text(ids, trim_padding=False)
     assert (1 - _cos(a, b)).max() < 1e-6
     assert (1 - _cos(a, co.embed_texts(ids, W, s))).max() < COS_TOL
+
+
+def test_single_request_runs_without_layernorm_launches(b32):
+    """One image / one prompt at a time (the reference's regime, backend/app/utils.py:76-77,88-97): every GEMM of a layer is on
+    the weight-streaming skinny kernel, LayerNorm1/2 are folded into the QKV / FC1 weights and the residual GEMMs' epilogues
+    keep the bf16 rows + per-16-column statistics up to date — no per-layer LayerNorm launch is left. Same bar against the
+    oracle as every other path, and against the separate-LayerNorm form of the same request."""
+    from mmiss_amd import _lib
+
+    enc, W, co = b32
+    s = co.VIT_B32
+    rng = np.random.Generator(np.random.Philox(41))
+    px = rng.standard_normal((2, 3, 224, 224), dtype=np.float32)
+    px[1] = px[1] * 0.05 + 4.0                      # a row with a large mean / std ratio
+    ids = co.synthetic_text_ids(1, 77, s.t_vocab, s.eos_token_id, seed=42, bos=49406)
+
+    def kernels_of(fn):
+        _lib.prof_reset(); _lib.prof_enable(True)
+        try:
+            out = fn()
+        finally:
+            _lib.prof_enable(False)
+        return out, {p["kernel"]: p["launches"] for p in _lib.prof_read()}
+
+    out1, k1 = kernels_of(lambda: enc.encode_image(px[:1]))
+    assert k1.get("gemm_skinny_lnfold_bias", 0) == 12 and k1.get("gemm_skinny_lnfold_qgelu", 0) == 11, k1
+    assert k1.get("layernorm", 0) <= 4, k1          # pre-LN, the pruned last layer's LN2, the head — no per-layer launches
+    out2 = enc.encode_image(px[1:2])
+    out_t, kt = kernels_of(lambda: enc.encode_text(ids))
+    assert kt.get("gemm_skinny_lnfold_bias", 0) == 12, kt
+    ref = co.embed_images(px, W, s)
+    d_img = (1 - _cos(np.concatenate([out1, out2]), ref)).max()
+    d_txt = (1 - _cos(out_t, co.embed_texts(ids, W, s))).max()
+    _lib.set_option("skinny_fold", 0)
+    try:
+        plain1, kp = kernels_of(lambda: enc.encode_image(px[:1]))
+    finally:
+        _lib.set_option("skinny_fold", 1)
+    assert "gemm_skinny_lnfold_bias" not in kp and kp.get("layernorm", 0) >= 24, kp
+    print("single request, folded skinny GEMMs: 1 - cos vs oracle image %.2e text %.2e; vs separate LayerNorm %.2e"
+          % (d_img, d_txt, (1 - _cos(out1, plain1)).max()))
+    assert d_img < COS_TOL and d_txt < COS_TOL
+    assert (1 - _cos(out1, plain1)).max() < 2e-5

@@ -36,7 +36,8 @@ for _ in range(n):
 torch.cuda.synchronize()
 print({"ms_per_encode_only": round((time.perf_counter() - t0) / n * 1e3, 4)})
 
-# ---- the same request captured in a HIP graph (torch.cuda.CUDAGraph on the library's stream = torch's current stream)
+# ---- the encode captured in a HIP graph (torch.cuda.CUDAGraph on the library's stream = torch's current stream). The query is
+# not capturable since round 2: its exactness guard reads one flag back to decide on the host whether to widen.
 try:
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
@@ -44,13 +45,11 @@ try:
     with torch.cuda.stream(s):
         for _ in range(3):
             enc.encode_image(px, out=emb)
-            lab, dist, cnt = index.query(emb, 10)
         torch.cuda.synchronize()
+        ref = emb.clone()
         with torch.cuda.graph(g, stream=s):
             enc.encode_image(px, out=emb)
-            lab, dist, cnt = index.query(emb, 10)
     torch.cuda.synchronize()
-    ref_lab = index.query(emb, 10)[0].clone()
     for _ in range(10):
         g.replay()
     torch.cuda.synchronize()
@@ -58,7 +57,6 @@ try:
     for _ in range(n):
         g.replay()
     torch.cuda.synchronize()
-    print({"ms_per_request_graph_replay": round((time.perf_counter() - t0) / n * 1e3, 4),
-           "same_result": bool(torch.equal(lab, ref_lab))})
+    print({"ms_per_encode_graph_replay": round((time.perf_counter() - t0) / n * 1e3, 4), "same_result": bool(torch.equal(emb, ref))})
 except Exception as e:  # noqa: BLE001
     print({"graph_capture_failed": repr(e)})
