@@ -26,30 +26,26 @@ __global__ void convert_2d_bf16_kernel(const float* __restrict__ src, uint16_t* 
     }
 }
 
-// dst row r = src row rowmap[r]; rows of row_bytes (a multiple of 16) — compacts the pooled rows for the last layer
-__global__ void gather_rows16_kernel(const char* __restrict__ src, const int32_t* __restrict__ rowmap,
-                                     char* __restrict__ dst, int n, int row_bytes) {
-    const int chunks = row_bytes >> 4;
-    const int64_t total = (int64_t)n * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / chunks), c = (int)(i - (int64_t)r * chunks);
-        *reinterpret_cast<u32x4*>(dst + (size_t)r * row_bytes + (size_t)c * 16) =
-            *reinterpret_cast<const u32x4*>(src + (size_t)rowmap[r] * row_bytes + (size_t)c * 16);
-    }
-}
-
-// the same for a bf16 residual stream: dst (f32, row stride d) row r = widened src (bf16) row rowmap[r]
-__global__ void gather_rows_bf16_f32_kernel(const uint16_t* __restrict__ src, const int32_t* __restrict__ rowmap,
-                                            float* __restrict__ dst, int n, int d) {
+// The pruned last layer's two gathers in one launch: ctxc row r = ctx row rowmap[r] (bf16), xc row r = the residual row
+// rowmap[r] as f32 — copied from x32, or widened from x16 when the stream is bf16. d % 4 == 0.
+__global__ void gather_pooled_kernel(const uint16_t* __restrict__ ctx, uint16_t* __restrict__ ctxc, const float* __restrict__ x32,
+                                     const uint16_t* __restrict__ x16, float* __restrict__ xc, const int32_t* __restrict__ rowmap,
+                                     int n, int d) {
     const int chunks = d >> 2;
     const int64_t total = (int64_t)n * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / chunks), c = (int)(i - (int64_t)r * chunks);
-        const u32x2 v = *reinterpret_cast<const u32x2*>(src + (size_t)rowmap[r] * d + (size_t)c * 4);
+        const size_t so = (size_t)rowmap[r] * d + (size_t)c * 4, dofs = (size_t)r * d + (size_t)c * 4;
+        *reinterpret_cast<u32x2*>(ctxc + dofs) = *reinterpret_cast<const u32x2*>(ctx + so);
         f32x4 o;
-        o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xFFFF0000u);
-        o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xFFFF0000u);
-        *reinterpret_cast<f32x4*>(dst + (size_t)r * d + (size_t)c * 4) = o;
+        if (x16) {
+            const u32x2 v = *reinterpret_cast<const u32x2*>(x16 + so);
+            o[0] = __uint_as_float(v[0] << 16); o[1] = __uint_as_float(v[0] & 0xFFFF0000u);
+            o[2] = __uint_as_float(v[1] << 16); o[3] = __uint_as_float(v[1] & 0xFFFF0000u);
+        } else {
+            o = *reinterpret_cast<const f32x4*>(x32 + so);
+        }
+        *reinterpret_cast<f32x4*>(xc + dofs) = o;
     }
 }
 
@@ -68,6 +64,8 @@ struct Tower {
     // workspaces (lazily allocated for max_batch)
     int ws_batch = 0;
     DevBuf x, h, qkv, ctx, u, pooled, proj_out, pool_row, out_stage, taps;
+    int pool_B = -1, pool_T = -1;   // vision: pool_row currently holds b * pool_T for b < pool_B (written once per shape)
+    bool embed_stats = false;       // this call's embedding stage already left xb + row statistics (layernorm_stats_kernel)
     DevBuf xc, hc, ctxc, uc;  // compact [Bp, *] buffers of the pooled rows (last-layer pruning)
     DevBuf stats;             // [Mp][hidden/64][2] partial row (sum, sumsq) for the LayerNorm-fused GEMMs
     DevBuf xb;                // bf16 copy of the residual stream (A operand of the LayerNorm-folded GEMMs)
@@ -223,6 +221,7 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     MM_TRY(alloc_zero(tw.pooled, (size_t)Bp * d * 2));
     MM_TRY(alloc_zero(tw.proj_out, (size_t)Bp * proj_dim * 4));
     MM_TRY(alloc_zero(tw.pool_row, (size_t)max_batch * 4));
+    tw.pool_B = tw.pool_T = -1;
     MM_TRY(alloc_zero(tw.out_stage, (size_t)max_batch * proj_dim * 4));
     MM_TRY(alloc_zero(tw.xc, (size_t)Bp * d * 4));
     MM_TRY(alloc_zero(tw.hc, (size_t)Bp * d * 2));
@@ -245,18 +244,25 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
 }
 
 // the transformer stack shared by both towers; x holds the embeddings on entry
+// LayerNorm placement for a call of M token rows: 0 separate kernels, 1 staged (experiments), 2 folded into the GEMMs
+static int pick_ln_mode(const mmiss_encoder* e, const Tower& tw, int M, bool& fp8) {
+    int mode = e->ln_mode;
+    if (mode < 0) {
+        const int forced = mmiss_option("ln_mode", -1);
+        mode = forced >= 0 ? forced : ((M >= mmiss_option("ln_fold_min_rows", 6000) && tw.hidden <= 768) ? 2 : 0);
+    }
+    fp8 = e->precision == MMISS_PREC_FP8 && tw.fp8_ready && tw.h8.p && M >= mmiss_option("fp8_min_rows", 1024);
+    if (fp8) mode = 0;  // the fp8 GEMMs take their A operand from the MXFP8 LayerNorm kernel
+    return mode;
+}
+
 int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) {
     const int d = tw.hidden, M = B * tw.T;
     const float eps = e->cfg.ln_eps;
     // per-GEMM tile height (fills the 256 CUs x 2 blocks evenly) and the row count padded to it
     // the LayerNorm-fused / folded GEMMs (ln_mode 1, 2) exist for the 128-column tiles only
-    int mode = e->ln_mode;
-    if (mode < 0) {
-        const int forced = mmiss_option("ln_mode", -1);
-        mode = forced >= 0 ? forced : ((M >= mmiss_option("ln_fold_min_rows", 6000) && d <= 768) ? 2 : 0);
-    }
-    const bool fp8 = e->precision == MMISS_PREC_FP8 && tw.fp8_ready && tw.h8.p && M >= mmiss_option("fp8_min_rows", 1024);
-    if (fp8) mode = 0;  // the fp8 GEMMs take their A operand from the MXFP8 LayerNorm kernel
+    bool fp8 = false;
+    const int mode = pick_ln_mode(e, tw, M, fp8);
     const bool plain = mode == 0;
     int bm_qkv = plain ? gemm_pick_variant(M, 3 * d) : gemm_pick_bm(M, 3 * d);
     int bm_d = plain ? gemm_pick_variant(M, d) : gemm_pick_bm(M, d);
@@ -328,7 +334,9 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
                            tw.xb.as<uint16_t>(), M, d);
         MM_HIP(hipGetLastError());
     }
-    if (fuse || fold || resid16) {  // (separate-LayerNorm mode with a bf16 stream: only the bf16 copy is used)
+    const bool have_embed_stats = tw.embed_stats;  // (the vision embedding stage's pre-LN already wrote xb + statistics)
+    tw.embed_stats = false;
+    if ((fuse || fold || resid16) && !have_embed_stats) {  // (separate-LayerNorm mode with a bf16 stream: only the bf16 copy is used)
         MM_PROF("row_stats", st, 3.0 * M * d, (fold ? 6.0 : 4.0) * M * d);
         hipLaunchKernelGGL(row_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(),
                            (fold || resid16) ? tw.xb.as<uint16_t>() : nullptr, M, d, parts);
@@ -376,14 +384,10 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         if (prune && l == tw.layers - 1) {
             const int Bp = (int)round_up(B, 128);
             const int grid = (B * d / 4 + 255) / 256;
-            hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid), dim3(256), 0, st, tw.ctx.as<char>(),
-                               tw.pool_row.as<int32_t>(), tw.ctxc.as<char>(), B, d * 2);
-            if (resid16)
-                hipLaunchKernelGGL(gather_rows_bf16_f32_kernel, dim3(grid), dim3(256), 0, st, tw.xb.as<uint16_t>(),
-                                   tw.pool_row.as<int32_t>(), tw.xc.as<float>(), B, d);
-            else
-                hipLaunchKernelGGL(gather_rows16_kernel, dim3(grid), dim3(256), 0, st, tw.x.as<char>(),
-                                   tw.pool_row.as<int32_t>(), tw.xc.as<char>(), B, d * 4);
+            // pooled rows of the attention output (bf16) and of the residual stream (f32, or widened bf16) in ONE launch
+            hipLaunchKernelGGL(gather_pooled_kernel, dim3(grid), dim3(256), 0, st, tw.ctx.as<uint16_t>(), tw.ctxc.as<uint16_t>(),
+                               resid16 ? nullptr : tw.x.as<float>(), resid16 ? tw.xb.as<uint16_t>() : nullptr,
+                               tw.xc.as<float>(), tw.pool_row.as<int32_t>(), B, d);
             MM_HIP(hipGetLastError());
             ep = GemmEpi{};
             ep.out = tw.xc.p; ep.bias = L.bo.as<float>(); ep.ldo = d; ep.m_valid = B;
@@ -510,11 +514,32 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
         ep.splitk_ws = tw.splitk.as<float>(); ep.splitk_ws_bytes = tw.splitk.bytes;
     }
     MM_TRY(launch_gemm(st, MMISS_EPI_PATCH_F32, bm_p, e->patches.p, e->patch_w.p, ep, Mpp, d, e->Kp));
-    // pre_layrnorm, in place on the fp32 residual stream (HF:modeling_clip.py:640)
-    MM_TRY(launch_layernorm(st, tw.x.as<float>(), e->pre_g.as<float>(), e->pre_b.as<float>(), tw.x.p, false, nullptr,
-                            B * tw.T, d, e->cfg.ln_eps));
-    hipLaunchKernelGGL(vision_pool_rows_kernel, dim3((B + 255) / 256), dim3(256), 0, st, tw.pool_row.as<int32_t>(), B,
-                       tw.T);
+    // pre_layrnorm, in place on the fp32 residual stream (HF:modeling_clip.py:640); when the layers will want the bf16 copy
+    // and the row statistics of the result (folded LayerNorm, bf16 residual stream) the same pass writes them
+    {
+        const int M = B * tw.T;
+        bool fp8 = false;
+        const int mode = pick_ln_mode(e, tw, M, fp8);
+        const bool want = !e->record_taps && d % 128 == 0 &&
+                          (mode == 2 || (mode == 0 && M >= mmiss_option("ln_fold_min_rows", 6000))) &&
+                          mmiss_option("prelayernorm_stats", 1) != 0;
+        if (want) {
+            MM_PROF("layernorm", st, 10.0 * M * d, (double)M * d * 10);
+            hipLaunchKernelGGL(layernorm_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), e->pre_g.as<float>(),
+                               e->pre_b.as<float>(), tw.xb.as<uint16_t>(), tw.stats.as<float>(), M, d, d / 64, e->cfg.ln_eps);
+            MM_HIP(hipGetLastError());
+            tw.embed_stats = true;
+        } else {
+            MM_TRY(launch_layernorm(st, tw.x.as<float>(), e->pre_g.as<float>(), e->pre_b.as<float>(), tw.x.p, false, nullptr, M, d,
+                                    e->cfg.ln_eps));
+        }
+    }
+    if (tw.pool_B < B || tw.pool_T != tw.T) {  // token 0 of every image: the same table until the shape changes
+        const int nb = tw.ws_batch > B ? tw.ws_batch : B;
+        hipLaunchKernelGGL(vision_pool_rows_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, tw.pool_row.as<int32_t>(), nb, tw.T);
+        tw.pool_B = nb;
+        tw.pool_T = tw.T;
+    }
     MM_TRY(run_layers(e, tw, B, false, st));
     MM_TRY(run_head(e, tw, B, out_dev, st));
     tw.last_B = B;
