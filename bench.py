@@ -407,6 +407,30 @@ def main():
                          "the partly empty last round of tiles and the store burst of every GEMM. NOT the headline value: kernel "
                          "durations overlap in this mode, so the roofline object is measured one batch at a time"}
 
+    # ---------------------------------------------------------------- the same step with the fp8 GEMMs (N = 1 only, opt-in path)
+    b32_fp8 = None
+    if rank == 0 and world == 1 and not args.no_text:
+        enc.encode_image(pixels, out=emb)
+        ref16 = emb.clone()
+        enc.set_precision("fp8")
+        try:
+            for _ in range(3):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            fdt = (time.perf_counter() - t0) / args.steps
+            cos8 = float((1.0 - (emb * ref16).sum(dim=1)).max().item())
+        finally:
+            enc.set_precision("bf16")
+        b32_fp8 = {"images_per_s": round(B / fdt, 1), "ms_per_step": round(fdt * 1e3, 3),
+                   "max_1_minus_cos_vs_bf16_path": cos8,
+                   "note": "set_precision('fp8'): QKV / FC1 / FC2 on v_mfma_scale_f32_16x16x128_f8f6f4 (MXFP8 activations, e4m3 weights "
+                           "with per-channel scales), everything else as in the bf16 step. Opt-in: e4m3's 3 mantissa bits put the towers "
+                           "0.5-4e-3 from the bf16 path (text tower outside the 1e-3 tolerance), DESIGN.md 3b. NOT the headline value"}
+
     # ---------------------------------------------------------------- the reference's own checkpoint geometry (N = 1 only)
     l14 = None
     if rank == 0 and world == 1 and not args.no_text:
@@ -495,7 +519,7 @@ def main():
             "exactness": dict(index.guard_stats(), note="queries served by the step's index / of them not provable from the "
                               "first pass and widened (mmiss_index_guard_stats)"),
             "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest,
-            "two_batches_in_flight": lanes, "l14": l14, "cpu_baseline": cpu,
+            "two_batches_in_flight": lanes, "fp8_gemms": b32_fp8, "l14": l14, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
