@@ -444,14 +444,20 @@ def main():
         ol = torch.empty(BL, 768, device=dev)
 
         def timed(fn, warm, iters):
+            """Mean time per call over `iters` calls, the better of two passes (one pass of eight 17 ms calls is short enough
+            for a single host-side stall to cost 15 %: seen once in this round's runs)."""
             for _ in range(warm):
                 fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / iters
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / iters
+                best = dt if best is None or dt < best else best
+            return best
 
         dt_img = timed(lambda: enc_l.encode_image(xl, out=ol), 3, 8)
         idl = np.full((BT, 248), 49407, dtype=np.int32)
