@@ -44,6 +44,14 @@ int mmiss_dbg_gemm_time(int device, int epi, int variant, const void* A, const v
                         const float* bias, const float* aux, int32_t M, int32_t N, int32_t K,
                         int32_t p0, int32_t p1, int32_t iters, float* ms_per_launch);
 
+/* the persistent 256 x 256 tile GEMM (csrc/gemm_bf16_p256.h) in isolation: epi 1 / 2 = bias / bias + QuickGELU -> bf16,
+ * 7 / 8 = the same behind a LayerNorm folded into W (ln_stats f32 [M][K/64][2] partial (sum, sumsq) per 64 columns,
+ * aux = c [N], bias = b' [N]). M % 256 == 0 (rows >= m_valid land in row M - 1), N % 256 == 0, K % 256 == 0.
+ * iters > 0 and ms_per_launch != NULL: HIP-event time of `iters` back-to-back launches. */
+int mmiss_dbg_gemm_p256(int device, void* hip_stream, int epi, const void* A, const void* W, void* out,
+                        const float* bias, const float* aux, const float* ln_stats, float ln_eps, int32_t M, int32_t N,
+                        int32_t K, int32_t m_valid, int32_t iters, float* ms_per_launch);
+
 /* record the residual stream after every layer during encode calls (for mmiss_encoder_tap 0..L) */
 struct mmiss_encoder;
 int mmiss_dbg_encoder_record_taps(struct mmiss_encoder* enc, int on);

@@ -20,6 +20,8 @@ MMISS_F16 = 1
 MMISS_PREC_BF16 = 0
 MMISS_PREC_FP8 = 1
 MMISS_PREC_BF16_F32RESID = 2
+MMISS_TOWER_VISION = 0
+MMISS_TOWER_TEXT = 1
 
 EPI_F32, EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RESID_F32, EPI_PATCH_F32 = range(5)
 
@@ -60,6 +62,7 @@ SIGNATURES = {
     "mmiss_encoder_set_weight": (_I, [_P, C.c_char_p, _P, _I64, C.POINTER(_I)]),
     "mmiss_encoder_finalize": (_I, [_P]),
     "mmiss_encoder_set_precision": (_I, [_P, _I32]),
+    "mmiss_encoder_set_tower_precision": (_I, [_P, _I32, _I32]),
     "mmiss_encoder_set_stream": (_I, [_P, _P, _I32]),
     "mmiss_encode_image": (_I, [_P, _P, _I32, _P]),
     "mmiss_encode_image_u8": (_I, [_P, _P, _I32, _P]),
@@ -89,6 +92,7 @@ SIGNATURES = {
     "mmiss_prof_read": (_I, [C.c_char_p, C.c_size_t]),
     # mmiss_debug.h
     "mmiss_dbg_gemm": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32]),
+    "mmiss_dbg_gemm_p256": (_I, [_I, _P, _I, _P, _P, _P, _P, _P, _P, C.c_float, _I32, _I32, _I32, _I32, _I32, _P]),
     "mmiss_dbg_gemm_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32,
                                  C.POINTER(C.c_float)]),
     "mmiss_dbg_layernorm": (_I, [_I, _P, _P, _P, _P, _P, _I32, _I32, _I32, C.c_float]),

@@ -177,14 +177,21 @@ class ClipEncoder:
             self.set_precision(precision)
 
     def set_precision(self, precision: str) -> None:
-        """"bf16" (default): bf16 GEMM operands, f32 accumulation; large calls (>= ~6000 token rows, hidden <= 768) also keep
-        the residual stream in bf16 (1 - cos vs the fp32 oracle 5e-5 instead of 5e-6, 4-5 % faster). "bf16-f32resid": the
-        residual stream f32 at every batch size. "fp8": the QKV / FC1 / FC2 projections on the block-scaled fp8 matrix cores
-        (e4m3 operands, f32 accumulation; mmiss_encoder_set_precision) — BASELINE configs[4]. Bar for all: 1 - cos <= 1e-3
-        (fp8 does not meet it in general)."""
+        """"bf16" (default): bf16 GEMM operands, f32 accumulation; large calls (>= ~6000 token rows) also keep the residual
+        stream in bf16 (1 - cos vs the fp32 oracle 5e-5 instead of 5e-6, 4-5 % faster). "bf16-f32resid": the residual
+        stream f32 at every batch size. "fp8": the QKV / FC1 / FC2 projections of the VISION tower on the block-scaled fp8
+        matrix cores (e4m3 operands, f32 accumulation; mmiss_encoder_set_precision) - BASELINE configs[4]; the text tower
+        stays bf16 under this setting (its fp8 form is outside the tolerance). Bar for all of them: 1 - cos <= 1e-3."""
         code = {"bf16": _lib.MMISS_PREC_BF16, "fp8": _lib.MMISS_PREC_FP8, "bf16-f32resid": _lib.MMISS_PREC_BF16_F32RESID}[precision]
         _lib.check(self._lib.mmiss_encoder_set_precision(self._h, code))
         self.precision = precision
+
+    def set_tower_precision(self, tower: str, precision: str) -> None:
+        """One tower ("vision" / "text") to "bf16" or "fp8" (mmiss_encoder_set_tower_precision). fp8 on the text tower is an
+        explicit opt-in: it measures 1 - cos = 3-4e-3 against the fp32 oracle, outside the 1e-3 tolerance."""
+        t = {"vision": _lib.MMISS_TOWER_VISION, "text": _lib.MMISS_TOWER_TEXT}[tower]
+        code = {"bf16": _lib.MMISS_PREC_BF16, "fp8": _lib.MMISS_PREC_FP8}[precision]
+        _lib.check(self._lib.mmiss_encoder_set_tower_precision(self._h, t, code))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state: Dict[str, "np.ndarray"]) -> Tuple[int, int]:

@@ -10,14 +10,14 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-COS_TOL = 1e-3      # BASELINE.json north_star tolerance: what the bf16 path is held to
+COS_TOL = 1e-3      # BASELINE.json north_star tolerance: what EVERY default setting is held to, fp8 included
 # e4m3 carries 3 mantissa bits: every product of an fp8 GEMM has a relative rounding error of ~5 % rms (two operands of
-# 2^-3 / sqrt(12) each), independent across k, so every GEMM OUTPUT carries ~5 % noise whatever the scaling scheme; a
-# residual stream built from such outputs ends 3-8 % off, i.e. 1 - cos = eps^2 / 2 ~ 5e-4 .. 3e-3. Measured here: 3.5e-4
-# (vision, where the patch embedding dominates the stream) and 3.3e-3 (text) at 4 layers of the L/14 geometry. The fp8 path
-# therefore does NOT meet the 1e-3 tolerance in general; it is opt-in (default precision stays bf16) and held to its own,
-# measured bar. See DESIGN.md "fp8 path".
-COS_TOL_FP8 = 5e-3
+# 2^-3 / sqrt(12) each), independent across k, so every GEMM OUTPUT carries ~5 % noise whatever the scaling scheme. The
+# vision stream is dominated by the (bf16) patch embedding and ends 5e-4 from the oracle at full ViT-L/14 depth: inside the
+# tolerance, asserted below at COS_TOL. The text stream is built almost entirely from GEMM outputs and ends 3.3-3.9e-3 away:
+# OUTSIDE the tolerance — so set_precision("fp8") does not touch the text tower; fp8 there is an explicit opt-in
+# (set_tower_precision("text", "fp8")) that the tests run, print and bound loosely WITHOUT any parity claim.
+TEXT_FP8_OPT_IN_SANITY = 1e-2
 
 
 def _cos(a, b):
@@ -152,8 +152,10 @@ def _fp8_vs_bf16_vs_oracle(shape, seed, B_img, B_txt, T):
     px = rng.standard_normal((B_img, 3, shape.v_image, shape.v_image), dtype=np.float32)
     ids = co.synthetic_text_ids(B_txt, T, shape.t_vocab, shape.eos_token_id, seed=seed + 2)
     out = {}
-    for prec in ("bf16", "fp8"):
-        enc = ClipEncoder(ClipShape.from_any(shape), max_batch_image=B_img, max_batch_text=B_txt, precision=prec)
+    for prec in ("bf16", "fp8", "fp8+text"):
+        enc = ClipEncoder(ClipShape.from_any(shape), max_batch_image=B_img, max_batch_text=B_txt, precision=prec.split("+")[0])
+        if prec == "fp8+text":
+            enc.set_tower_precision("text", "fp8")     # explicit opt-in, outside the tolerance (mmiss.h)
         enc.load_state_dict(W)
         out[prec] = (enc.encode_image(px), enc.encode_text(ids, trim_padding=False))
         enc.close()
@@ -162,7 +164,9 @@ def _fp8_vs_bf16_vs_oracle(shape, seed, B_img, B_txt, T):
 
 def test_longclip_l14_geometry_fp8_vs_oracle(env):
     """The reference model's own geometry (d = 1024 / 16 heads / T = 257 vision, d = 768 / T = 248 text) at 4 layers:
-    8 images = 2056 rows and 8 texts = 1984 rows, both above the fp8 threshold. fp8 and bf16 against the fp32 oracle."""
+    8 images = 2056 rows and 8 texts = 1984 rows, both above the fp8 threshold. set_precision("fp8") = vision tower on the
+    fp8 GEMMs, text tower on the bf16 kernels: BOTH towers within 1e-3 of the fp32 oracle. The text opt-in is run and
+    printed next to it."""
     import dataclasses
     from mmiss_amd import _lib
     from oracle import clip_oracle as co
@@ -171,11 +175,42 @@ def test_longclip_l14_geometry_fp8_vs_oracle(env):
     (W, px, ids, out, co), kern = _with_kernels(lambda: _fp8_vs_bf16_vs_oracle(s, 31, 8, 8, 248))
     assert kern.get("gemm_fp8_bias", 0) > 0 and kern.get("gemm_fp8_qgelu_mx", 0) > 0 and kern.get("gemm_fp8_bias_resid", 0) > 0, kern
     ref_i, ref_t = co.embed_images(px, W, s), co.embed_texts(ids, W, s)
-    for prec in ("bf16", "fp8"):
-        di, dt = 1 - _cos(out[prec][0], ref_i), 1 - _cos(out[prec][1], ref_t)
-        print(prec, "image 1-cos max", di.max(), "text 1-cos max", dt.max())
-        tol = COS_TOL if prec == "bf16" else COS_TOL_FP8
-        assert di.max() < tol and dt.max() < tol, (prec, di, dt)
+    d = {}
+    for prec in ("bf16", "fp8", "fp8+text"):
+        d[prec] = ((1 - _cos(out[prec][0], ref_i)).max(), (1 - _cos(out[prec][1], ref_t)).max())
+        print(prec, "image 1-cos max %.2e text 1-cos max %.2e" % d[prec])
+    assert max(d["bf16"]) < COS_TOL, d
+    assert max(d["fp8"]) < COS_TOL, d                                   # the shipped fp8 setting, both towers
+    np.testing.assert_array_equal(out["fp8"][1], out["bf16"][1])        # ... whose text tower IS the bf16 path
+    assert d["fp8"][0] > d["bf16"][0]                                   # ... and whose vision tower really ran in fp8
+    np.testing.assert_array_equal(out["fp8+text"][0], out["fp8"][0])
+    assert d["bf16"][1] < d["fp8+text"][1] < TEXT_FP8_OPT_IN_SANITY, d   # opt-in: ran in fp8, finite; NOT a parity claim
+
+
+def test_text_tower_fp8_is_opt_in_only(env):
+    """The kernels a text call launches under set_precision("fp8") are the bf16 ones; only set_tower_precision("text",
+    "fp8") brings the fp8 GEMMs in, and setting it back removes them again."""
+    import dataclasses
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.LONGCLIP_L14, v_layers=1, t_layers=2, t_vocab=2000, eos_token_id=1999)
+    W = co.init_weights(s, seed=71)
+    ids = co.synthetic_text_ids(8, 248, s.t_vocab, s.eos_token_id, seed=72)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=2, max_batch_text=8, precision="fp8")
+    enc.load_state_dict(W)
+    base, kern = _with_kernels(lambda: enc.encode_text(ids, trim_padding=False))
+    assert not any(k.startswith("gemm_fp8") for k in kern), kern
+    enc.set_tower_precision("text", "fp8")
+    _, kern8 = _with_kernels(lambda: enc.encode_text(ids, trim_padding=False))
+    assert kern8.get("gemm_fp8_bias", 0) > 0, kern8
+    enc.set_tower_precision("text", "bf16")
+    again, kern16 = _with_kernels(lambda: enc.encode_text(ids, trim_padding=False))
+    assert not any(k.startswith("gemm_fp8") for k in kern16), kern16
+    np.testing.assert_array_equal(again, base)
+    with pytest.raises(KeyError):
+        enc.set_tower_precision("audio", "fp8")
+    enc.close()
 
 
 def _with_kernels(fn):
@@ -217,7 +252,7 @@ def test_fp8_residual_stream_layer_by_layer(env):
     print("fp8 per-layer max rel err", [round(r, 4) for r in rel], "1-cos", float((1 - _cos(out, ref)).max()))
     assert max(rel) < 0.15, rel                      # bounded per layer (bf16 path: < 0.03), no blow-up with depth
     assert rel[-1] < 3 * max(rel[1], 0.01), rel      # ... and not compounding: the last layer is no worse than ~3x the first
-    assert (1 - _cos(out, ref)).max() < COS_TOL_FP8
+    assert (1 - _cos(out, ref)).max() < COS_TOL
     enc.close()
 
 
@@ -249,8 +284,11 @@ def test_small_calls_fall_back_to_bf16_kernels(env):
 
 def test_longclip_l14_full_depth_vision_bf16_and_fp8(env):
     """BASELINE configs[4] geometry at FULL depth: the reference model's vision tower (ViT-L/14: 24 layers, d = 1024,
-    16 heads, T = 257, proj 768; backend/app/utils.py:16-17), seeded weights, 8 images = 2056 token rows (fp8 kernels
-    active), against the fp32 oracle: bf16 within the north_star tolerance, fp8 within its own measured bar."""
+    16 heads, T = 257, proj 768; backend/app/utils.py:16-17), seeded weights, against the fp32 oracle at the north_star
+    tolerance, bf16 AND fp8:
+      * 8 images in one call = 2056 token rows (fp8 kernels active, f32 residual stream);
+      * the config's own batch, 128 images in one call = 32 896 token rows (bf16 residual stream, banded tile order, the
+        tile heights of the large grid) whose first 8 images are the same 8 — a different dispatch of every GEMM."""
     import dataclasses
     from mmiss_amd.encoder import ClipEncoder, ClipShape
     from oracle import clip_oracle as co
@@ -258,16 +296,22 @@ def test_longclip_l14_full_depth_vision_bf16_and_fp8(env):
     s = dataclasses.replace(co.LONGCLIP_L14, t_layers=1, t_vocab=1000, eos_token_id=999)  # text tower cut: vision only here
     W = co.init_weights(s, seed=51)
     rng = np.random.Generator(np.random.Philox(52))
-    px = rng.standard_normal((8, 3, 224, 224), dtype=np.float32)
-    ref = co.embed_images(px, W, s)
-    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=8, max_batch_text=2)
+    px = rng.standard_normal((128, 3, 224, 224), dtype=np.float32)
+    ref = co.embed_images(px[:8], W, s)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=128, max_batch_text=2)
     enc.load_state_dict(W)
-    d16 = 1 - _cos(enc.encode_image(px), ref)
+    d16 = 1 - _cos(enc.encode_image(px[:8]), ref)
+    d16_128 = 1 - _cos(enc.encode_image(px)[:8], ref)
     enc.set_precision("fp8")
-    (out8, kern) = _with_kernels(lambda: enc.encode_image(px))
+    (out8, kern) = _with_kernels(lambda: enc.encode_image(px[:8]))
     d8 = 1 - _cos(out8, ref)
+    (out8_128, kern128) = _with_kernels(lambda: enc.encode_image(px))
+    d8_128 = 1 - _cos(out8_128[:8], ref)
     enc.close()
-    print("L/14 24 layers: 1-cos bf16", float(d16.max()), "fp8", float(d8.max()))
+    print("L/14 24 layers: 1-cos vs oracle  bs 8: bf16 %.2e fp8 %.2e   bs 128 (first 8): bf16 %.2e fp8 %.2e"
+          % (d16.max(), d8.max(), d16_128.max(), d8_128.max()))
     assert kern.get("gemm_fp8_bias", 0) == 24 and kern.get("gemm_fp8_bias_resid", 0) == 23, kern
-    assert d16.max() < COS_TOL, d16
-    assert d8.max() < COS_TOL_FP8, d8
+    assert kern128.get("gemm_fp8_bias", 0) == 24 and kern128.get("gemm_fp8_bias_resid16", 0) == 23, kern128
+    assert d16.max() < COS_TOL and d16_128.max() < COS_TOL, (d16, d16_128)
+    assert d8.max() < COS_TOL and d8_128.max() < COS_TOL, (d8, d8_128)
+    assert np.isfinite(out8_128).all() and np.abs(np.linalg.norm(out8_128, axis=1) - 1).max() < 1e-5

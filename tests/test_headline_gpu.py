@@ -322,7 +322,7 @@ def test_l14_full_depth_bf16_residual_stream_in_the_separate_layernorm_mode():
     enc.set_precision("bf16-f32resid")
     out32, kern32 = _kernels_of(lambda: enc.encode_image(px))
     assert "layernorm16" not in kern32 and kern32.get("gemm_bf16_bias_resid_k1024", 0) == 23, kern32
-    # fp8 GEMMs (QKV / FC1 / FC2) on the same bf16 stream: its own, wider bar (tests/test_fp8_gpu.py)
+    # fp8 GEMMs (QKV / FC1 / FC2) on the same bf16 stream: the same 1e-3 bar (tests/test_fp8_gpu.py)
     enc.set_precision("fp8")
     out8, kern8 = _kernels_of(lambda: enc.encode_image(px))
     enc.close()
@@ -332,4 +332,4 @@ def test_l14_full_depth_bf16_residual_stream_in_the_separate_layernorm_mode():
     print("L/14 24 layers, 6168 rows: 1 - cos vs oracle bf16 stream %.2e, f32 stream %.2e, fp8 GEMMs on the bf16 stream %.2e"
           % (d16, d32, d8))
     assert d16 < 3e-4 and d32 < 3e-5, (d16, d32)   # (bar: COS_TOL = 1e-3; CPU simulation 3-8e-5 / 2-3e-6)
-    assert d8 < 5e-3, d8
+    assert d8 < 1e-3, d8
