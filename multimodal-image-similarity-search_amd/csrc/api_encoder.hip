@@ -296,6 +296,14 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         const int64_t tiles = (int64_t)((M + 255) / 256) * (N / 256), rounds = (tiles + 255) / 256;
         return tiles * 100 >= rounds * 256 * 85;
     };  // (workspace rows are padded to round_up(M, 128) + 192 >= round_up(M, 256))
+    // Persistent form of that tile (gemm_bf16_p256.h, round 3): one workgroup per CU walks its tiles as one K stream with the
+    // epilogue in registers. Taken for the wide GEMMs (QKV, FC1) of calls with at least 256 tiles (one per CU); option
+    // gemm_p256 = 0 turns it off, n > 1 = minimum tile count.
+    const int p256_min = mmiss_option("gemm_p256", 1);
+    auto p256 = [&](int epi, int N) {
+        if (p256_min == 0 || !gemm256p_ok(epi, padded(256), N, d)) return false;
+        return (int64_t)(padded(256) / 256) * (N / 256) >= (p256_min > 1 ? p256_min : 256);
+    };
     // split-K scratch for the narrow long-K GEMM (FC2) while its grid is far below the CU count
     if (gemm_splitk_candidate((int64_t)((M + 127) / 128) * (d / GEMM_BN), tw.mlp))
         MM_TRY(tw.splitk.ensure((size_t)8 * (round_up(M, 128) + 192) * d * 4));  // any tile height's row padding
@@ -355,7 +363,9 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         if (fold) {
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
-            if (fold256(3 * d)) {
+            if (p256(MMISS_EPI_LNFOLD_BF16, 3 * d)) {
+                MM_TRY(launch_gemm256p(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, padded(256), 3 * d, d));
+            } else if (fold256(3 * d)) {
                 MM_TRY(launch_gemm256(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, padded(256), 3 * d, d));
             } else {
                 MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_BF16, bm_qkv, tw.xb.p, L.wqkv_f.p, ep, padded(bm_qkv), 3 * d, d));
@@ -383,7 +393,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             else
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
-            if (use256(3 * d)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_BF16, tw.h.p, L.wqkv.p, ep, padded(256), 3 * d, d));
+            if (p256(MMISS_EPI_BIAS_BF16, 3 * d)) MM_TRY(launch_gemm256p(st, MMISS_EPI_BIAS_BF16, tw.h.p, L.wqkv.p, ep, padded(256), 3 * d, d));
+            else if (use256(3 * d)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_BF16, tw.h.p, L.wqkv.p, ep, padded(256), 3 * d, d));
             else MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
         }
         MM_TRY(launch_attention(st, tw.qkv.p, tw.ctx.p, B, tw.T, tw.heads, causal));
@@ -425,7 +436,9 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         if (fold) {
             ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
-            if (fold256(tw.mlp) && mmiss_option("gemm_256_fold_mlp", 0)) {  // (A/B knob: 78 -> 84 us at 12 800 rows, off)
+            if (p256(MMISS_EPI_LNFOLD_QGELU_BF16, tw.mlp)) {
+                MM_TRY(launch_gemm256p(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, padded(256), tw.mlp, d));
+            } else if (fold256(tw.mlp) && mmiss_option("gemm_256_fold_mlp", 0)) {  // (A/B knob: 78 -> 84 us at 12 800 rows, off)
                 MM_TRY(launch_gemm256(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, padded(256), tw.mlp, d));
             } else {
                 MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, bm_mlp, tw.xb.p, L.w1_f.p, ep, padded(bm_mlp), tw.mlp, d));
@@ -462,7 +475,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             else
             MM_TRY(launch_layernorm(st, tw.x.as<float>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, true, nullptr, M,
                                     d, eps));
-            if (use256(tw.mlp)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_QGELU_BF16, tw.h.p, L.w1.p, ep, padded(256), tw.mlp, d));
+            if (p256(MMISS_EPI_BIAS_QGELU_BF16, tw.mlp)) MM_TRY(launch_gemm256p(st, MMISS_EPI_BIAS_QGELU_BF16, tw.h.p, L.w1.p, ep, padded(256), tw.mlp, d));
+            else if (use256(tw.mlp)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_QGELU_BF16, tw.h.p, L.w1.p, ep, padded(256), tw.mlp, d));
             else MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.h.p, L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
         }
         ep = GemmEpi{};

@@ -65,8 +65,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 }
 
 __device__ __forceinline__ float quick_gelu(float x) {
-    // x * sigmoid(1.702 x)  — HF:activations.py:117-123
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
+    // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x))  — HF:activations.py:117-123. One multiply, v_exp_f32 (= 2^x),
+    // v_rcp_f32: the two transcendentals are what an epilogue of 128 values per lane costs (8 of its ~28 cycles per value each).
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
 }
 
 // XCD-aware, bijective block remap (guide §5 "XCD swizzle must be bijective"): blocks that share an

@@ -1,34 +1,45 @@
-// gemm_bf16_p256.h — PERSISTENT form of the 256x256x64 phase-pipelined bf16 GEMM (gemm_bf16_256.h) for the wide GEMMs
-// of the towers (QKV, FC1: N >= 1536), same contract C[M,N] = A[M,K] * W[N,K]^T + fused epilogue.
+// gemm_bf16_p256.h — PERSISTENT 256x256x64 bf16 GEMM for the wide GEMMs of the towers (QKV, FC1: N >= 1536), same
+// contract as gemm_bf16.h: C[M,N] = A[M,K] * W[N,K]^T + fused epilogue (bf16 out; bias / bias + QuickGELU, optionally behind
+// a LayerNorm folded into W).
 //
-// Why: as one workgroup per tile the 256x256 kernel pays, per tile, a pipeline fill from cold, a drain,
-// and an epilogue that goes through the staging LDS — and at 12 800 rows every workgroup is in its epilogue at the same
-// time, so nothing hides the stores (QKV 55 us for 2 rounds of a 20 us K loop; FC1 could not use the tile at all).
-// Here the grid is one workgroup per CU (256) and the workgroup OWNS its tile schedule:
-//   * its tiles form ONE continuous K-tile stream (the structure of gemm256_strip_kernel): the loads of the next tile's
-//     first two K-tiles are issued by the ordinary t+1 / t+2 prefetch of the current tile's last two K-tiles;
-//   * the epilogue runs from REGISTERS while those loads fly: LayerNorm fold / bias / QuickGELU, bf16 pack, two
-//     v_permlane16_swap per 16x32 block so that every lane owns 8 consecutive columns, and 16-byte global stores that
-//     are never waited for (64-byte row segments, two adjacent instructions per 128-byte line). No LDS traffic, so the
-//     staging buffers stay live across the tile boundary;
+// Why (measurements of round 3 in profiles/gemm_p256_r03.txt): the one-tile-per-workgroup 256x256 kernel
+// (gemm_bf16_256.h) pays per tile a pipeline fill from cold, a drain and an epilogue through the staging LDS, all of it with
+// every workgroup of the chip in the same state at the same time; and its K loop spends its time NEXT TO the matrix pipe,
+// not in it (PMC: matrix cores busy 45 % of a wave's lifetime; ablations: MFMAs, fragment reads, staging and barriers add
+// up instead of overlapping). Here the grid is one workgroup per CU and the workgroup owns its tile schedule:
+//   * its tiles form ONE continuous K-tile stream: the loads of the next tile's first two K-tiles are issued by the
+//     ordinary t+1 / t+2 prefetch of the current tile's last two K-tiles, the epilogue runs while they fly;
+//   * two barriers per phase — [fragment reads + one slot's staging + counted wait] B [16 MFMAs] B — and the waves of the
+//     lower tile half (wm = 1: waves 4-7, the SIMD partners of waves 0-3) run ONE barrier behind, so that on every SIMD one
+//     wave issues MFMAs while its partner reads fragments and stages (guide: the 256^2 8-phase template's staggered wave
+//     groups; MICROARCH "two waves per SIMD", item 9);
+//   * the loop is unrolled over the two staging buffers: every LDS address is base register + immediate, every LDS-DMA
+//     source a scalar base + a per-lane 32-bit offset computed once, staging is unconditional (past the end of the stream
+//     it re-reads the last tile into free slots) and the waits are plain immediates — the first version of this loop spent
+//     0.3 us per K-tile on scalar bookkeeping alone (tools/gemm_p256_ablate.py);
 //   * everything the epilogue needs from memory arrives by LDS-DMA as well — the tile's 256 bias / c values (one 4-byte
 //     piece per wave) and, in the folded-LayerNorm mode, the raw (sum, sumsq) partials of its 256 rows (K/256 16-byte
 //     pieces per wave), finalised to (mean, rstd) by 256 threads in a wait-free phase of K-tile 2 — because an ordinary
 //     load beside LDS-DMA makes hipcc drain the whole pipeline (guide §5, trap (b));
-//   * the stores and those pieces count in vmcnt (in issue order, guide: `s_waitcnt vmcnt(N)`), so the four counted waits
-//     that follow an epilogue allow P256_EX more operations in flight; from the fifth wait on every such operation is
-//     older than the slot being waited for and the plain count applies again;
+//   * the epilogue's stores and those pieces count in vmcnt (in issue order), so the four counted waits that follow an
+//     epilogue allow EX more operations in flight; from the fifth wait on every such operation is older than the slot
+//     being waited for and the plain count applies again;
 //   * tile order: XCD x (blockIdx % 8) works on 32 logically consecutive tiles per round, 8 row blocks x 4 column tiles
-//     in the banded order of tile_order() (12 operand panels per XCD and round instead of ~3 + all of W); the tiles of
-//     the last, partial round are dealt round-robin over the XCDs.
+//     in the banded order of tile_order(); the tiles of the last, partial round are dealt round-robin over the XCDs.
 #pragma once
 #include "gemm_bf16_256.h"
 
 #define P256_BC (8 * G256_SLOT)       // 2 x 2 KB: bias [256] f32 + c [256] f32 of the current / next tile
 #define P256_TABLE (P256_BC + 4096)   // 256 x (mean, rstd)
-#define P256_RAW (P256_TABLE + 2048)  // 256 rows x K/64 x (sum, sumsq) f32, as they lie in memory
+#define P256_RAW (P256_TABLE + 2048)  // 256 rows x K/64 x (sum, sumsq) f32, as they lie in memory; the epilogue's patches
 
-template <int EPI, int XP>  // XP = 16-byte statistic pieces per wave and tile (K / 256 in the folded modes, else 0)
+// DBG (timing experiments only, EXPERIMENTS builds, tools/gemm_p256_ablate.py; results are wrong by construction), a
+// compile-time mask: 1 = no MFMAs, 2 = no staging inside the loop, 4 = no fragment reads, 8 = every tile loads tile (0, 0)
+// (operands L2-hot), 16 = no epilogue, 32 = epilogue without its stores, 64 = no barriers
+// STYLE: how the epilogue gets from "a lane holds 4 consecutive columns of one row" to wide stores: 0 = a 16 x 64 transpose
+// per wave through a private 2 KB LDS patch, whole 128-byte rows per store instruction; 1 = two v_permlane16_swap per
+// 16 x 32 block, 8 consecutive columns per lane, 64-byte row segments (two adjacent instructions per line).
+template <int EPI, int XP, int STYLE = 0, int DBG = 0>  // XP = 16-byte statistic pieces per wave and tile (K / 256 when folded, else 0)
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W, int M,
                                                           int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -43,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int nbm = M >> 8, nbn = N >> 8;
-    const int nt = K / GEMM_BK;
+    const int nt = K / GEMM_BK;  // even (K % 128 == 0)
 
     // ---- this workgroup's tile list: ordinal i -> logical tile -> (bm, bn)
     const int T = nbm * nbn, G = gridDim.x;
@@ -58,25 +69,36 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         tile_order(L, nbm, nbn, ep.m_fast, bm, bn);
     };
 
+    // ---- LDS-DMA sources, buffer form (one descriptor per operand): per-lane byte offset of the lane's row / chunk, computed
+    // once (ONE VGPR per operand), everything else — tile, K-tile, m / n half, 8-row piece — in the scalar offset.
+    // Slot row r of an A slot is the activation row (r>>6)*128 + mq*64 + (r&63) of the tile, of a W slot the weight row
+    // (r>>5)*64 + nq*32 + (r&31); a wave stages slot rows 16*wave .. 16*wave+15; XOR swizzle on the source chunk.
+    // LDS slot order: A m0 (buffer 0, 1), A m1 (0, 1), W n0 (0, 1), W n1 (0, 1), so that ONE base register per operand and
+    // k step reaches every slot of the operand with a 16-bit immediate.
     const int r_in = lane >> 3, p = lane & 7;
     const int src_chunk = (p ^ r_in) * 8;
-    const int a_row0 = (wave >> 2) * 128 + (wave & 3) * 16 + r_in;
-    const int w_row0 = (wave >> 1) * 64 + (wave & 1) * 16 + r_in;
-    const size_t a_lane = (size_t)a_row0 * K + src_chunk, w_lane = (size_t)w_row0 * K + src_chunk;
-    // stage slot `which` (0 = A m0, 1 = A m1, 2 = W n0, 3 = W n1) of buffer b from K-tile kt of the tile at (Ab, Wb)
-    auto stage = [&](int which, int b, const __bf16* Ab, const __bf16* Wb, int kt, bool live) {
-        if (!live) return;
-        char* dst = smem + (b * 4 + which) * G256_SLOT + wave * 2048;
-        if (which < 2) {
-            const __bf16* src = Ab + a_lane + (size_t)(which * 64) * K + (size_t)kt * GEMM_BK;
-            glds16(src, dst);
-            glds16(src + (size_t)8 * K, dst + 1024);
-        } else {
-            const __bf16* src = Wb + w_lane + (size_t)((which - 2) * 32) * K + (size_t)kt * GEMM_BK;
-            glds16(src, dst);
-            glds16(src + (size_t)8 * K, dst + 1024);
-        }
-    };
+    const int a_vo = (((wave >> 2) * 128 + (wave & 3) * 16 + r_in) * K + src_chunk) * 2;
+    const int w_vo = (((wave >> 1) * 64 + (wave & 1) * 16 + r_in) * K + src_chunk) * 2;
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(W), 0, 0x7fffffff, 0x00020000);
+    const int row8 = 8 * K * 2;  // bytes between a slot's two 8-row pieces
+    const int stage_dst = wave * 2048;
+#define P256_SLOT(which, b) (((which) * 2 + (b)) * G256_SLOT)
+#define P256_BLDS(srd, vo, so, dst) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 16, vo, so, 0, 0)
+#define P256_STAGE(which, b, oA, oW)                                                                         \
+    if constexpr (!((DBG & 2) != 0)) {                                                                      \
+        char* dst_ = smem + P256_SLOT(which, b) + stage_dst;                                                \
+        if constexpr ((which) < 2) {                                                                        \
+            const int so_ = (oA) + ((which) & 1) * 8 * row8;                                                \
+            P256_BLDS(srdA, a_vo, so_, dst_);                                                               \
+            P256_BLDS(srdA, a_vo, so_ + row8, dst_ + 1024);                                                 \
+        } else {                                                                                            \
+            const int so_ = (oW) + ((which) & 1) * 4 * row8;                                                \
+            P256_BLDS(srdW, w_vo, so_, dst_);                                                               \
+            P256_BLDS(srdW, w_vo, so_ + row8, dst_ + 1024);                                                 \
+        }                                                                                                   \
+    }
     // what the epilogue of tile (bm, bn) reads from memory, by LDS-DMA: 1 + XP pieces per wave
     auto stage_x = [&](int bm, int bn, int par) {
         const float* src = ((FOLD && wave >= 4) ? ep.aux : ep.bias) + bn * 256 + (wave & 3) * 64 + lane;
@@ -89,6 +111,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         }
     };
 
+    // ---- fragment reads: one base per operand and k step + immediate (slot, 16-row sub-tile)
+    uint32_t ab[2], wb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        ab[s] = (wm * 64 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
+        wb[s] = P256_SLOT(2, 0) + (wn * 32 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
+    }
     frag am[4][2];
     frag wq[2][2][2];
     f32x4 acc[4][8];
@@ -96,151 +125,226 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int a_off[4][2], w_off[2][2];
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-        const int row = wm * 64 + mf * 16 + fr;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) a_off[mf][s] = row * 128 + (((4 * s + fg) ^ (row & 7)) << 4);
+
+#define P256_READ_A(b, mq)                                                                                   \
+    if constexpr (!((DBG & 4) != 0)) {                                                                      \
+        _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) {                                                  \
+            am[mf][0] = *reinterpret_cast<const frag*>(smem + ab[0] + P256_SLOT(mq, b) + mf * 2048);        \
+            am[mf][1] = *reinterpret_cast<const frag*>(smem + ab[1] + P256_SLOT(mq, b) + mf * 2048);        \
+        }                                                                                                   \
     }
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf) {
-        const int row = wn * 32 + nf * 16 + fr;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) w_off[nf][s] = row * 128 + (((4 * s + fg) ^ (row & 7)) << 4);
+#define P256_READ_W(b, nq)                                                                                   \
+    if constexpr (!((DBG & 4) != 0)) {                                                                      \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                                  \
+            wq[nq][nf][0] = *reinterpret_cast<const frag*>(smem + wb[0] + P256_SLOT(nq, b) + nf * 2048);    \
+            wq[nq][nf][1] = *reinterpret_cast<const frag*>(smem + wb[1] + P256_SLOT(nq, b) + nf * 2048);    \
+        }                                                                                                   \
+    }
+#define P256_MMA(mq, nq)                                                                                     \
+    if constexpr ((DBG & 1) != 0) {                                                                         \
+        _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) asm volatile("" ::"v"(am[mf][0]), "v"(am[mf][1]));  \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) asm volatile("" ::"v"(wq[nq][nf][0]), "v"(wq[nq][nf][1])); \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                    \
+            _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) asm volatile("" : "+v"(acc[(nq) * 2 + nf][(mq) * 4 + mf])); \
+    } else {                                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
+            _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                \
+                _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                            \
+                    acc[(nq) * 2 + nf][(mq) * 4 + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
+                        wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf], 0, 0, 0);              \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    }
+// counted wait: 10 = the five slot loads (2 pieces each) that stay in flight; POST = the stores and pieces of the
+// previous tile's epilogue are younger than the slot waited for
+#define P256_WAIT(POST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((POST) ? 10 + EX : 10) : "memory")
+#define P256_BARRIER()                                                \
+    {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        if constexpr (!((DBG & 64) != 0)) __builtin_amdgcn_s_barrier(); \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+// The slots the LATE half (wm = 1) reads in a phase are restaged by the early half right after the next barrier: its reads
+// must have completed before that barrier (the early half's own reads complete a whole barrier earlier, with its MFMAs).
+#define P256_LATE_READS_DONE() \
+    if (wm == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// One K-tile out of buffer B: four phases [reads + one slot's staging + wait] B [16 MFMAs] B. The wait that retires a slot
+// sits in the read part of the phase BEFORE the one that reads it (both halves' waits and a barrier precede both halves'
+// reads); a slot is restaged in the phase AFTER its last read. P0 / P1 / P3 = post-epilogue form of the three waits; FIN =
+// this is K-tile 2 of a tile (the raw statistics landed behind the waits of K-tile 1).
+#define P256_KTILE(B, P0, P1, P3, FIN)                                                                       \
+    {                                                                                                       \
+        P256_READ_A(B, 0);                                                                                  \
+        P256_READ_W(B, 0);                                                                                  \
+        P256_STAGE(1, (B) ^ 1, oA1, oW1); /* A m1 of K-tile t+1 */                                          \
+        P256_LATE_READS_DONE();                                                                             \
+        P256_WAIT(P0);                    /* retires W n1 of this K-tile */                                 \
+        P256_BARRIER();                                                                                     \
+        P256_MMA(0, 0);                                                                                     \
+        P256_BARRIER();                                                                                     \
+        P256_READ_W(B, 1);                                                                                  \
+        P256_STAGE(0, B, oA2, oW2);       /* A m0 of K-tile t+2 */                                          \
+        P256_LATE_READS_DONE();                                                                             \
+        P256_WAIT(P1);                    /* retires A m1 of this K-tile */                                 \
+        P256_BARRIER();                                                                                     \
+        P256_MMA(0, 1);                                                                                     \
+        P256_BARRIER();                                                                                     \
+        P256_READ_A(B, 1);                                                                                  \
+        P256_STAGE(2, B, oA2, oW2);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
+        P256_LATE_READS_DONE();                                                                             \
+        P256_BARRIER();                                                                                     \
+        P256_MMA(1, 1);                                                                                     \
+        P256_BARRIER();                                                                                     \
+        P256_STAGE(3, B, oA2, oW2);       /* W n1 of K-tile t+2 */                                          \
+        if constexpr (FOLD && (FIN)) {                                                                      \
+            if (kp == 1 && tid < 256) finalize_stats();                                                     \
+        }                                                                                                   \
+        P256_WAIT(P3);                    /* retires A m0 / W n0 of the next K-tile */                      \
+        P256_BARRIER();                                                                                     \
+        P256_MMA(1, 0);                                                                                     \
+        P256_BARRIER();                                                                                     \
+        /* position t+1 becomes the old t+2; t+2 moves on one K-tile (into the next tile, or wraps in the last one) */ \
+        oA1 = oA2; oW1 = oW2;                                                                               \
+        if (++k2 == nt) {                                                                                   \
+            k2 = 0;                                                                                         \
+            if (o2 + 1 < mine) ++o2;                                                                        \
+            int bm_, bn_;                                                                                   \
+            tile_of(o2, bm_, bn_);                                                                          \
+            oA2 = bm_ * 256 * K * 2;                                                                        \
+            oW2 = bn_ * 256 * K * 2;                                                                        \
+            if constexpr ((DBG & 8) != 0) { oA2 = 0; oW2 = 0; }                                             \
+        } else {                                                                                            \
+            oA2 += GEMM_BK * 2; oW2 += GEMM_BK * 2;                                                         \
+        }                                                                                                   \
     }
 
-#define P256_READ_A(b, mq)                                                                          \
-    {                                                                                               \
-        const char* sl = smem + ((b) * 4 + (mq)) * G256_SLOT;                                       \
-        _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) {                                          \
-            am[mf][0] = *reinterpret_cast<const frag*>(sl + a_off[mf][0]);                          \
-            am[mf][1] = *reinterpret_cast<const frag*>(sl + a_off[mf][1]);                          \
-        }                                                                                           \
-    }
-#define P256_READ_W(b, nq)                                                                          \
-    {                                                                                               \
-        const char* sl = smem + ((b) * 4 + 2 + (nq)) * G256_SLOT;                                   \
-        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                          \
-            wq[nq][nf][0] = *reinterpret_cast<const frag*>(sl + w_off[nf][0]);                      \
-            wq[nq][nf][1] = *reinterpret_cast<const frag*>(sl + w_off[nf][1]);                      \
-        }                                                                                           \
-    }
-#define P256_MMA(mq, nq)                                                                            \
-    {                                                                                               \
-        __builtin_amdgcn_s_setprio(1);                                                              \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                               \
-            _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                        \
-                _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                    \
-                    acc[(nq) * 2 + nf][(mq) * 4 + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
-                        wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf], 0, 0, 0);      \
-        __builtin_amdgcn_s_setprio(0);                                                              \
-    }
-// counted wait: 10 = the five slot loads (2 pieces each) that stay in flight; `post` = the stores and pieces of the
-// previous tile's epilogue are younger than the slot waited for; !live2 = stream tail (fewer loads were issued)
-#define P256_WAIT(live2, post)                                                           \
-    {                                                                                    \
-        if (!(live2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
-        else if (post) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 + EX) : "memory");    \
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                           \
-    }
-#define P256_BARRIER()                         \
-    {                                          \
-        __builtin_amdgcn_sched_barrier(0);     \
-        __builtin_amdgcn_s_barrier();          \
-        __builtin_amdgcn_sched_barrier(0);     \
-    }
+    auto finalize_stats = [&]() {  // thread t: (mean, rstd) of the tile's row t from its K/64 partial (sum, sumsq)
+        const f32x4* st = reinterpret_cast<const f32x4*>(smem + P256_RAW + tid * (XP * 32));
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < XP * 2; ++q) { const f32x4 v = st[q]; s1 += v[0] + v[2]; s2 += v[1] + v[3]; }
+        const float kd = (float)K;
+        const float mean = s1 / kd;
+        const float var = fmaxf(s2 / kd - mean * mean, 0.f);
+        float* tb = reinterpret_cast<float*>(smem + P256_TABLE);
+        tb[2 * tid] = mean;
+        tb[2 * tid + 1] = 1.0f / sqrtf(var + ep.ln_eps);
+    };
 
-    // ---- stream state: the tile being computed (ordinal ti) and the tiles the positions t+1 / t+2 lie in
-    int ti = 0, kt = 0, cbm, cbn;
+    // ---- stream state
+    int cbm, cbn;
     tile_of(0, cbm, cbn);
-    const __bf16 *A0 = A + (size_t)cbm * 256 * K, *W0 = W + (size_t)cbn * 256 * K;  // tile of position t
-    const __bf16 *A1 = A0, *W1 = W0, *A2 = A0, *W2 = W0;                            // tiles of positions t+1, t+2
-    int o1 = 0, k1 = 1, o2 = 0, k2 = 2;                                             // (nt >= 4: both still in tile 0)
+    int oA1 = cbm * 256 * K * 2, oW1 = cbn * 256 * K * 2;  // byte offsets of K-tile 0 of tile 0, then of position t+1
+    if constexpr ((DBG & 8) != 0) { oA1 = 0; oW1 = 0; }
+    int oA2 = oA1 + GEMM_BK * 2, oW2 = oW1 + GEMM_BK * 2;
+    int o2 = 0, k2 = 1;
     const int dump_row = M - 1;  // rows >= m_valid are stored to the last pad row (the store COUNT must not depend on data)
 
+    // prologue: K-tile 0 completely, K-tile 1 except its A m1 slot (staged by phase 0 of K-tile 0)
     stage_x(cbm, cbn, 0);
-    stage(0, 0, A0, W0, 0, true); stage(2, 0, A0, W0, 0, true); stage(3, 0, A0, W0, 0, true); stage(1, 0, A0, W0, 0, true);
-    stage(0, 1, A0, W0, 1, true); stage(2, 1, A0, W0, 1, true); stage(3, 1, A0, W0, 1, true);
-    P256_WAIT(true, false);
+    {
+        char* d0 = smem + stage_dst;
+        P256_BLDS(srdA, a_vo, oA1, d0 + P256_SLOT(0, 0)); P256_BLDS(srdA, a_vo, oA1 + row8, d0 + P256_SLOT(0, 0) + 1024);
+        P256_BLDS(srdW, w_vo, oW1, d0 + P256_SLOT(2, 0)); P256_BLDS(srdW, w_vo, oW1 + row8, d0 + P256_SLOT(2, 0) + 1024);
+        P256_BLDS(srdW, w_vo, oW1 + 4 * row8, d0 + P256_SLOT(3, 0)); P256_BLDS(srdW, w_vo, oW1 + 5 * row8, d0 + P256_SLOT(3, 0) + 1024);
+        P256_BLDS(srdA, a_vo, oA1 + 8 * row8, d0 + P256_SLOT(1, 0)); P256_BLDS(srdA, a_vo, oA1 + 9 * row8, d0 + P256_SLOT(1, 0) + 1024);
+        P256_BLDS(srdA, a_vo, oA2, d0 + P256_SLOT(0, 1)); P256_BLDS(srdA, a_vo, oA2 + row8, d0 + P256_SLOT(0, 1) + 1024);
+        P256_BLDS(srdW, w_vo, oW2, d0 + P256_SLOT(2, 1)); P256_BLDS(srdW, w_vo, oW2 + row8, d0 + P256_SLOT(2, 1) + 1024);
+        P256_BLDS(srdW, w_vo, oW2 + 4 * row8, d0 + P256_SLOT(3, 1)); P256_BLDS(srdW, w_vo, oW2 + 5 * row8, d0 + P256_SLOT(3, 1) + 1024);
+    }
+    // position t+1 = K-tile 1 (its A m1 slot is still to come), t+2 = K-tile 2
+    oA1 = oA2; oW1 = oW2;
+    oA2 += GEMM_BK * 2; oW2 += GEMM_BK * 2;
+    k2 = 2;
+    P256_WAIT(false);  // all but the five youngest slot loads: A m0 / W n0 of K-tile 0 (and the epilogue pieces) have landed
     P256_BARRIER();
+    if (wm == 1) P256_BARRIER();  // the lower half runs one barrier behind from here on
 
-    const int Tk = mine * nt;
-    for (int t = 0; t < Tk; ++t) {
-        const int b = t & 1;
-        const bool live2 = (t + 2 < Tk), live1 = (t + 1 < Tk);
-        const bool post0 = ti > 0 && kt == 0, post1 = ti > 0 && kt == 1;
-        // phase 0: quadrant (m0, n0)
-        P256_READ_A(b, 0);
-        P256_READ_W(b, 0);
-        stage(1, b ^ 1, A1, W1, k1, live1);
-        P256_MMA(0, 0);
-        P256_WAIT(live2, post0 || post1);
-        P256_BARRIER();
-        // phase 1: quadrant (m0, n1)
-        P256_READ_W(b, 1);
-        stage(0, b, A2, W2, k2, live2);
-        P256_MMA(0, 1);
-        P256_WAIT(live2, post0);
-        P256_BARRIER();
-        // phase 2: quadrant (m1, n1); no wait here — the place for the (mean, rstd) table of this tile's rows
-        P256_READ_A(b, 1);
-        stage(2, b, A2, W2, k2, live2);
-        if constexpr (FOLD) {
-            if (kt == 2 && tid < 256) {
-                const f32x4* st = reinterpret_cast<const f32x4*>(smem + P256_RAW + tid * (XP * 32));
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int q = 0; q < XP * 2; ++q) { const f32x4 v = st[q]; s1 += v[0] + v[2]; s2 += v[1] + v[3]; }
-                const float kd = (float)K;
-                const float mean = s1 / kd;
-                const float var = fmaxf(s2 / kd - mean * mean, 0.f);
-                float* tb = reinterpret_cast<float*>(smem + P256_TABLE);
-                tb[2 * tid] = mean;
-                tb[2 * tid + 1] = 1.0f / sqrtf(var + ep.ln_eps);
+    const int npair = nt >> 1;
+    for (int ti = 0; ti < mine; ++ti) {
+        for (int kp = 0; kp < npair; ++kp) {
+            if (kp == 0 && ti > 0) {
+                P256_KTILE(0, true, true, true, false);
+                P256_KTILE(1, true, false, false, false);
+            } else {
+                P256_KTILE(0, false, false, false, true);
+                P256_KTILE(1, false, false, false, false);
             }
         }
-        P256_MMA(1, 1);
-        P256_BARRIER();
-        // phase 3: quadrant (m1, n0) — operands already in registers
-        stage(3, b, A2, W2, k2, live2);
-        P256_MMA(1, 0);
-        P256_WAIT(live2, post0);
-        P256_BARRIER();
-        // advance the prefetch positions
-        if (++k1 == nt) {
-            k1 = 0; ++o1;
-            if (o1 < mine) { int bm, bn; tile_of(o1, bm, bn); A1 = A + (size_t)bm * 256 * K; W1 = W + (size_t)bn * 256 * K; }
-        }
-        if (++k2 == nt) {
-            k2 = 0; ++o2;
-            if (o2 < mine) { int bm, bn; tile_of(o2, bm, bn); A2 = A + (size_t)bm * 256 * K; W2 = W + (size_t)bn * 256 * K; }
-        }
-        if (++kt == nt) {
-            // ---- tile (cbm, cbn) is complete: epilogue from registers while the next tile's first K-tiles are in flight
-            const char* bc = smem + P256_BC + (ti & 1) * 2048;
-            f32x4 bias[4], cvec[4];
+        // ---- tile (cbm, cbn) is complete. The upper half waits one barrier for the lower half's last MFMAs, both run the
+        // epilogue side by side (while the next tile's first K-tiles are in flight), then the lower half falls one barrier
+        // behind again.
+        if (wm == 0) P256_BARRIER();
+        if constexpr (!((DBG & 16) != 0)) {
+        int lane_e = lane;  // (opaque here: what the epilogue derives from the lane id is not kept live through the K loop)
+        asm volatile("" : "+v"(lane_e));
+        const int fr = lane_e & 15, fg = lane_e >> 4;
+        const char* bc = smem + P256_BC + (ti & 1) * 2048;
+        f32x4 bias[4], cvec[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bias[i] = *reinterpret_cast<const f32x4*>(bc + (wn * 64 + i * 16 + 4 * fg) * 4);
-                if constexpr (FOLD) cvec[i] = *reinterpret_cast<const f32x4*>(bc + 1024 + (wn * 64 + i * 16 + 4 * fg) * 4);
+        for (int i = 0; i < 4; ++i) {
+            bias[i] = *reinterpret_cast<const f32x4*>(bc + (wn * 64 + i * 16 + 4 * fg) * 4);
+            if constexpr (FOLD) cvec[i] = *reinterpret_cast<const f32x4*>(bc + 1024 + (wn * 64 + i * 16 + 4 * fg) * 4);
+        }
+        float mu[8], rs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = 0.f; rs[j] = 1.f;
+            if constexpr (FOLD) {
+                const float* tb = reinterpret_cast<const float*>(smem + P256_TABLE) + 2 * (wm * 128 + j * 16 + fr);
+                mu[j] = tb[0]; rs[j] = tb[1];
             }
-            const float* tb = reinterpret_cast<const float*>(smem + P256_TABLE);
-            uint16_t* outp = reinterpret_cast<uint16_t*>(ep.out);
+        }
+        uint16_t* outp = reinterpret_cast<uint16_t*>(ep.out);
+        if constexpr (STYLE == 0) {
+            // Each wave transposes 16 rows x 64 columns at a time through a private 2 KB patch (its own share of the raw
+            // statistics area, dead since K-tile 2 and refilled by this wave only after these stores). 8-byte slot s of
+            // row r lies at slot s ^ 2 (r & 7): conflict-free both ways.
+            char* patch = smem + P256_RAW + wave * (XP >= 2 ? XP * 1024 : 2048);  // = the bytes stage_x() of THIS wave refills
+            const int rrow = lane_e >> 3, rchunk = lane_e & 7;
+            const int wr_off = fr * 128, wr_sw = 2 * (fr & 7);
+            const int col = cbn * 256 + wn * 64 + rchunk * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (FOLD) y[r] = rs[j] * (acc[i][j][r] - mu[j] * cvec[i][r]) + bias[i][r];
+                        else y[r] = acc[i][j][r] + bias[i][r];
+                        if constexpr (GELU) y[r] = quick_gelu(y[r]);
+                    }
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(y[0], y[1]);
+                    pk[1] = pack_bf16x2(y[2], y[3]);
+                    *reinterpret_cast<u32x2*>(patch + wr_off + (((i * 4 + fg) ^ wr_sw) << 3)) = pk;
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    const int row = rh * 8 + rrow;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((2 * rchunk) ^ (2 * (row & 7))) << 3));
+                    const int m = cbm * 256 + wm * 128 + j * 16 + row;
+                    if constexpr ((DBG & 32) != 0) asm volatile("" ::"v"(v));
+                    else *reinterpret_cast<u32x4*>(outp + (size_t)(m < ep.m_valid ? m : dump_row) * ep.ldo + col) = v;
+                }
+                __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next j
+            }
+        } else {
             const int colb = cbn * 256 + wn * 64 + (fg >> 1) * 8 + (fg & 1) * 16;  // + pair * 32
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int rl = wm * 128 + j * 16 + fr;
-                const int m = cbm * 256 + rl;
-                float mu = 0.f, rs = 1.f;
-                if constexpr (FOLD) { mu = tb[2 * rl]; rs = tb[2 * rl + 1]; }
                 uint32_t pk[4][2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float y[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if constexpr (FOLD) y[r] = rs * (acc[i][j][r] - mu * cvec[i][r]) + bias[i][r];
+                        if constexpr (FOLD) y[r] = rs[j] * (acc[i][j][r] - mu[j] * cvec[i][r]) + bias[i][r];
                         else y[r] = acc[i][j][r] + bias[i][r];
                         if constexpr (GELU) y[r] = quick_gelu(y[r]);
                     }
@@ -248,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                     pk[i][1] = pack_bf16x2(y[2], y[3]);
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+                const int m = cbm * 256 + wm * 128 + j * 16 + fr;
                 uint16_t* orow = outp + (size_t)(m < ep.m_valid ? m : dump_row) * ep.ldo + colb;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
@@ -257,37 +362,68 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                     const auto s1 = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
                     u32x4 v;
                     v[0] = s0[0]; v[1] = s1[0]; v[2] = s0[1]; v[3] = s1[1];
-                    *reinterpret_cast<u32x4*>(orow + pr * 32) = v;
+                    if constexpr ((DBG & 32) != 0) asm volatile("" ::"v"(v));
+                    else *reinterpret_cast<u32x4*>(orow + pr * 32) = v;
                 }
             }
-            kt = 0;
-            ++ti;
-            if (ti < mine) {
-                tile_of(ti, cbm, cbn);
-                stage_x(cbm, cbn, ti & 1);
-            }
+        }
+        }  // (epilogue)
+        if (ti + 1 < mine) {
+            tile_of(ti + 1, cbm, cbn);
+            stage_x(cbm, cbn, (ti + 1) & 1);
+            if (wm == 1) P256_BARRIER();
         }
     }
-    (void)A0; (void)W0;
+    if constexpr ((DBG & 16) != 0) {  // (ablation without epilogue: keep the accumulators alive)
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += acc[i][j];
+        if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.678f) reinterpret_cast<float*>(ep.out)[tid] = sum[0];
+    }
+    // the unconditional staging of the last K-tiles is still in flight: LDS must not be handed on with DMA writes pending
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#undef P256_STAGE
+#undef P256_SLOT
+#undef P256_BLDS
 #undef P256_READ_A
 #undef P256_READ_W
 #undef P256_MMA
 #undef P256_WAIT
 #undef P256_BARRIER
+#undef P256_KTILE
+#undef P256_LATE_READS_DONE
+
+template <int EPI, int XP, int STYLE, int DBG>
+static int launch_gemm256p_kern(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+    const int lds = P256_RAW + (XP >= 2 ? XP * 8192 : 16384);  // (the epilogue's transpose patches live in the raw-statistics area)
+    const int T = (M / 256) * (N / 256);
+    const int grid = T >= 256 ? 256 : T;
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p_kernel<EPI, XP, STYLE, DBG>), lds));
+    hipLaunchKernelGGL((gemm256p_kernel<EPI, XP, STYLE, DBG>), dim3(grid), dim3(512), lds, st, reinterpret_cast<const __bf16*>(A),
+                       reinterpret_cast<const __bf16*>(W), M, N, K, ep);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
 
 template <int EPI, int XP>
 static int launch_gemm256p_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep_in, int M, int N, int K) {
     GemmEpi ep = ep_in;
     if (ep.m_fast == 0) ep.m_fast = mmiss_option("gemm_p256_band", 8);
-    const int lds = P256_RAW + XP * 8192;
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p_kernel<EPI, XP>), lds));
-    const int T = (M / 256) * (N / 256);
-    const int grid = T >= 256 ? 256 : T;
-    hipLaunchKernelGGL((gemm256p_kernel<EPI, XP>), dim3(grid), dim3(512), lds, st, reinterpret_cast<const __bf16*>(A),
-                       reinterpret_cast<const __bf16*>(W), M, N, K, ep);
-    MM_HIP(hipGetLastError());
-    return MMISS_OK;
+#ifdef MMISS_EXPERIMENTS
+    if constexpr (EPI == MMISS_EPI_LNFOLD_QGELU_BF16 && XP == 3) {
+        const int dbg = mmiss_option("gemm_p256_dbg", 0);  // timing ablations (wrong results by construction)
+#define P256_DBG_CASE(D) if (dbg == D) return launch_gemm256p_kern<EPI, XP, 0, D>(st, A, W, ep, M, N, K);
+        P256_DBG_CASE(1) P256_DBG_CASE(2) P256_DBG_CASE(4) P256_DBG_CASE(8) P256_DBG_CASE(5) P256_DBG_CASE(6) P256_DBG_CASE(7)
+        P256_DBG_CASE(16) P256_DBG_CASE(32) P256_DBG_CASE(64) P256_DBG_CASE(23) P256_DBG_CASE(39) P256_DBG_CASE(87)
+#undef P256_DBG_CASE
+        if (dbg) MM_FAIL(MMISS_ERR_ARG, "gemm_p256_dbg = %d is not compiled", dbg);
+    }
+    if (mmiss_option("gemm_p256_style", 0) == 1) return launch_gemm256p_kern<EPI, XP, 1, 0>(st, A, W, ep, M, N, K);
+#endif
+    return launch_gemm256p_kern<EPI, XP, 0, 0>(st, A, W, ep, M, N, K);
 }
 
 // can this GEMM run on the persistent kernel? (bf16 output epilogues; the folded forms need K = 512 or 768: the raw
@@ -305,7 +441,6 @@ static int launch_gemm256p(hipStream_t st, int epi, const void* A, const void* W
     const bool fold = epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16;
     if (!ep.out || !ep.bias || (fold && (!ep.ln_stats || !ep.aux || ep.ln_parts * 64 != K)))
         MM_FAIL(MMISS_ERR_ARG, "gemm256p: missing operand (fold=%d parts=%d)", (int)fold, ep.ln_parts);
-    if (ep.m_valid < M && ep.m_valid > M - 1) MM_FAIL(MMISS_ERR_ARG, "gemm256p: no pad row");
     static const char* names[] = {"", "gemm_bf16_bias", "gemm_bf16_bias_qgelu"};
     const int mv = ep.m_valid < M ? ep.m_valid : M;
     const double bytes = 2.0 * ((double)mv * K + (double)N * K) + 2.0 * (double)mv * N;

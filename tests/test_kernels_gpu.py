@@ -407,3 +407,60 @@ def test_im2col(env, S, P):
     ref = px.reshape(B, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, Kreal).to(torch.bfloat16)
     assert torch.equal(out[:, :Kreal], ref)
     assert torch.equal(out[:, Kreal:].float(), torch.zeros(B * G * G, Kp - Kreal, device="cuda"))
+
+
+def _p256(env, epi, A, W, out, bias, aux=None, stats=None, m_valid=None, eps=1e-5):
+    torch, _lib, lib = env
+    M, K = A.shape
+    N = W.shape[0]
+    _lib.check(lib.mmiss_dbg_gemm_p256(0, None, epi, A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr(),
+                                       aux.data_ptr() if aux is not None else None,
+                                       stats.data_ptr() if stats is not None else None, eps, M, N, K,
+                                       M if m_valid is None else m_valid, 0, None))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,mv", [(512, 512, 256, 512), (2560, 2304, 768, 2560), (768, 1536, 512, 700),
+                                      (12800, 2304, 768, 12800), (12800, 3072, 768, 12750), (19712, 2048, 512, 19712)])
+def test_gemm_p256_persistent(env, M, N, K, mv):
+    """The persistent 256 x 256 kernel (gemm_bf16_p256.h): one tile per workgroup (T < 256 tiles), 1-2 and 2-3 tiles per
+    workgroup as ONE K stream (450 / 600 / 616 tiles: counted waits across the epilogue stores, LDS-DMA'd bias and
+    LayerNorm statistics, the partial last round), pad rows. Plain epilogues bit-identical to the one-tile-per-workgroup
+    256 x 256 kernel (same k order, same formula); folded-LayerNorm epilogues against an fp32 restatement. Repeated to
+    catch a schedule race."""
+    torch, _lib, lib = env
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, device="cuda", generator=g) * (1 + torch.rand(M, 1, device="cuda", generator=g)) + \
+        0.5 * torch.randn(M, 1, device="cuda", generator=g)
+    A = _bf16(x)
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    acc = A.float() @ W.float().T
+    for epi in (_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16):
+        want = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        _gemm(env, epi, A, W, want, bias=bias, bm=256)
+        r = acc + bias
+        if epi == _lib.EPI_BIAS_QGELU_BF16:
+            r = r * torch.sigmoid(1.702 * r)
+        assert torch.allclose(want.float(), r, rtol=2 ** -7, atol=2e-3)
+        for rep in range(3):
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            _p256(env, epi, A, W, out, bias, m_valid=mv)
+            assert torch.equal(out[:mv].view(torch.int16), want[:mv].view(torch.int16)), (epi, rep)
+            if mv < M:   # pad rows: untouched except the dump row M - 1
+                assert torch.isnan(out[mv:M - 1].float()).all() and torch.isfinite(out[M - 1].float()).all()
+    # folded LayerNorm: A = raw rows, W = gamma-folded weights, c[n] = sum_k W[n,k], statistics per 64 columns
+    a32 = A.float()
+    parts = a32.view(M, K // 64, 64)
+    stats = torch.stack([parts.sum(-1), (parts * parts).sum(-1)], dim=-1).contiguous()     # [M][K/64][2]
+    cvec = W.float().sum(1).contiguous()
+    mean = a32.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt((a32 * a32).mean(1, keepdim=True) - mean * mean + 1e-5)
+    ref = rstd * (acc - mean * cvec) + bias
+    for epi, r in ((7, ref), (8, ref * torch.sigmoid(1.702 * ref))):
+        if K not in (512, 768):
+            break            # (the raw statistics of a tile must fit beside the staging buffers: hidden 512 / 768 only)
+        for rep in range(3):
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            _p256(env, epi, A, W, out, bias, aux=cvec, stats=stats, m_valid=mv)
+            assert torch.allclose(out[:mv].float(), r[:mv], rtol=2 ** -7, atol=4e-3), (epi, rep, (out[:mv].float() - r[:mv]).abs().max())
