@@ -43,6 +43,8 @@ KERNEL_SYMBOL = {  # libmmiss kernel class -> symbol as rocprofv3 --kernel-trace
     "gemm_bf16_bias_qgelu": "gemm16_kernel<__bf16,BM,2>", "gemm_bf16_bias_resid": "gemm16_kernel<__bf16,BM,3>",
     "gemm_bf16_bias_resid16": "gemm16_kernel<__bf16,BM,9>",
     "gemm_bf16_lnfold_bias": "gemm256_kernel<__bf16,7> (>= 85 % tile fill) / gemm16_kernel<__bf16,BM,7>", "gemm_bf16_lnfold_qgelu": "gemm16_kernel<__bf16,BM,8>",
+    "gemm_bf16_lnfold_bias_p256": "gemm256p_kernel<7,K/256,0,0>", "gemm_bf16_lnfold_qgelu_p256": "gemm256p_kernel<8,K/256,0,0>",
+    "gemm_bf16_bias_p256": "gemm256p_kernel<1,0,0,0>", "gemm_bf16_bias_qgelu_p256": "gemm256p_kernel<2,0,0,0>",
     "gemm_bf16_patch": "gemm16_kernel<__bf16,BM,4>", "score_gemm_f16": "gemm16_kernel<_Float16,128,5>",
     "attention": "attention_kernel<2,false>",
     "layernorm": "layernorm_kernel<true>", "im2col": "im2col_kernel<false>",
@@ -133,8 +135,13 @@ def main():
     enc = ClipEncoder(VIT_B32, device=local_rank, max_batch_image=B, max_batch_text=B)
     enc.load_state_dict(W)
 
+    # Distinct images per step (configs[1] is 100k DISTINCT images): NROT batches, resident in HBM before the timed region,
+    # step i encodes batch i % NROT (seed 1234 + rank, consecutive draws). 154 MB each.
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    pixels = torch.randn(B, 3, 224, 224, device=dev, generator=gen)  # resident in HBM before the timed region
+    NROT = max(1, min(args.steps, 8))
+    pixel_batches = [torch.randn(B, 3, 224, 224, device=dev, generator=gen) for _ in range(NROT)]
+    pixels = pixel_batches[0]
+    step_no = [0]
     index = FlatIndex(D, "f16", device=local_rank, capacity=args.index_rows)
     rows = torch.randn(args.index_rows, D, device=dev, generator=gen)
     index.add(rows, np.arange(rank * args.index_rows, (rank + 1) * args.index_rows, dtype=np.int64))
@@ -143,7 +150,8 @@ def main():
     emb_all = torch.empty(world * B, D, device=dev) if world > 1 else emb
 
     def step():
-        enc.encode_image(pixels, out=emb)
+        enc.encode_image(pixel_batches[step_no[0] % NROT], out=emb)
+        step_no[0] += 1
         if world > 1:
             all_gather(emb_all, emb)                     # queries: every rank searches all N*256 embeddings in its shard
             lab, dst, _ = index.query(emb_all, K_TOP)
@@ -511,6 +519,9 @@ def main():
             "config": {"workload": "ViT-B/32 image encode bs=256 per GPU + cosine top-10 of every embedding vs a "
                                    f"{args.index_rows}x512 f16 flat index per GPU (BASELINE configs[1])",
                        "global_batch": world * B, "image": "3x224x224 f32 resident in HBM", "weights": "random-init seed 0",
+                       "images": f"{NROT} distinct batches of {B} N(0,1) images per rank resident in HBM, step i encodes batch i % {NROT} "
+                                 "(the full 100k-distinct-image ingest-then-query flow of configs[1] is "
+                                 "tests/test_headline_gpu.py::test_config1_100k_distinct_images_ingested_then_queried_back)",
                        "index_dtype": "f16", "k": K_TOP, "parallelism": f"dp{world}",
                        "flops_per_image": 8.818e9, "flops_per_image_executed": 8.298e9,
                        "pruning": "last layer: out-proj + MLP on the pooled (CLS) rows only",

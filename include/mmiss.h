@@ -218,6 +218,14 @@ int mmiss_index_query(mmiss_index* idx, const float* queries, int32_t Q, int32_t
  * scan pages read. No reference analogue (chromadb's HNSW is approximate above 100 rows).
  */
 int mmiss_index_guard_stats(mmiss_index* idx, int64_t out[4]);
+/*
+ * The same four counters and, in out[4], the queries that were still unproven after three widen rounds and went through
+ * the exhaustive canonical pass instead (the canonical distance of every row, the k best by (distance, label)): a plateau of
+ * more rows within the rounding bound of the k-th score than paging walks in reasonable time — e.g. > 10^5 copies of one
+ * placeholder image. Exact for any data; costs one pass over the index and one host selection per such query.
+ * out[5..7] are reserved (0).
+ */
+int mmiss_index_guard_stats_ex(mmiss_index* idx, int64_t out[8]);
 
 /* persistence of rows + labels (replaces chroma_data/, backend/app/utils.py:21,113) */
 int mmiss_index_save(mmiss_index* idx, const char* path);

@@ -138,16 +138,24 @@ class FlatCollection:
             return
         vec = np.memmap(jv, dtype=np.float32, mode="r") if os.path.exists(jv) and os.path.getsize(jv) else None
         autosave, self._autosave = self._autosave, False   # replay must not journal again
+        good_end = 0          # byte offset just behind the last committed record
+        torn = needs_newline = False
         try:
-            with open(jl) as f:
-                for line in f:
+            with open(jl, "rb") as f:
+                for raw in f:
                     try:
-                        rec = json.loads(line)
+                        rec = json.loads(raw.decode("utf-8"))
+                        if not isinstance(rec, dict) or "op" not in rec:
+                            raise ValueError("not a journal record")
                     except ValueError:
-                        break                                # a torn last line: the mutation was never committed
+                        torn = True                          # a torn last line: the mutation was never committed
+                        break
                     emb = None
                     if "offset" in rec:
                         o, n, d = rec["offset"] // 4, rec["rows"], rec["dim"]
+                        if vec is None or (o + n * d) > vec.shape[0]:
+                            torn = True                      # the commit line survived, its vectors did not: not committed
+                            break
                         emb = np.array(vec[o:o + n * d]).reshape(n, d)
                     if rec["op"] == "add":
                         self.add(rec["ids"], emb, rec.get("metadatas"), rec.get("documents"))
@@ -156,8 +164,20 @@ class FlatCollection:
                     elif rec["op"] == "delete":
                         self.delete(rec["ids"])
                     self._journal_rows = getattr(self, "_journal_rows", 0) + max(1, len(rec.get("ids", [])))
+                    good_end += len(raw)
+                    needs_newline = not raw.endswith(b"\n")   # (a complete record whose newline was cut off)
         finally:
             self._autosave = autosave
+        # Leave the file ending in a newline behind the last committed record: later appends would otherwise be glued to
+        # the torn bytes, become unparsable, and every mutation acknowledged after the crash would be lost at the next restart.
+        if torn or needs_newline:
+            with open(jl, "r+b") as f:
+                f.truncate(good_end)
+                if needs_newline:
+                    f.seek(good_end)
+                    f.write(b"\n")
+                f.flush()
+                os.fsync(f.fileno())
 
     def _load(self) -> None:
         with open(self._meta_path()) as f:

@@ -1,6 +1,7 @@
 // api_index.hip — C-ABI of the flat cosine index (the chromadb Collection's numeric half) and the two
 // stateless glue kernels (blend, shard merge).
 #include "common.h"
+#include <queue>
 #include "retrieval_kernels.h"
 #include "gemm_bf16_256.h"
 #include <algorithm>
@@ -23,7 +24,8 @@ struct mmiss_index {
     DevBuf flags, nflag_d, qmap, qmap64, qs2, cand2, cur2_s, cur2_r;
     DevBuf seed_s, seed_r, fcnt, fbuf_s, fbuf_g;  // threshold-filtered selection (Q > 128)
     int32_t* nflag_h = nullptr;  // pinned
-    int64_t stat_queries = 0, stat_flagged = 0, stat_rounds = 0, stat_pages = 0;
+    int64_t stat_queries = 0, stat_flagged = 0, stat_rounds = 0, stat_pages = 0, stat_exhaustive = 0;
+    DevBuf dist_all;  // exhaustive fallback: one canonical distance per row
     hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
 };
 
@@ -433,6 +435,60 @@ int read_nflag(mmiss_index* ix, hipStream_t st, int* n) {
     return MMISS_OK;
 }
 
+// Exhaustive canonical pass for the queries listed in `which`: canonical distance of every row (canonical_scan_kernel), the
+// k best by (distance, row) picked on the host (a bounded heap: O(N log k)), final ordering / labels / counts by the ordinary
+// rerank kernel with "nothing was left out" (tau = -inf).
+int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& which, int k, int64_t* d_lab, float* d_dist,
+                       int32_t* d_cnt) {
+    const int64_t N = ix->count;
+    const int D = ix->dim, KP = 32;
+    const int kk = (int)std::min<int64_t>(k, N);
+    const int kkpad = (int)round_up(std::max(kk, 1), KP);
+    if (which.empty() || N <= 0) return MMISS_OK;
+    MM_TRY(ix->dist_all.ensure((size_t)N * 4));
+    MM_TRY(ix->cand2.ensure((size_t)kkpad * 4));
+    MM_TRY(ix->qmap.ensure(4));
+    std::vector<float> dist((size_t)N);
+    std::vector<int32_t> cand((size_t)kkpad);
+    typedef std::pair<float, int32_t> Ent;  // (distance, row); NaN distances never enter
+    for (const int32_t q : which) {
+        {
+            MM_PROF("canonical_scan", st, 2.0 * N * D, (double)N * D * ix->elt);
+            const int grid = (int)std::min<int64_t>(8192, (N + 15) / 16);
+            if (ix->dtype == MMISS_F16)
+                hipLaunchKernelGGL(canonical_scan_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
+                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
+            else
+                hipLaunchKernelGGL(canonical_scan_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
+                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
+            MM_HIP(hipGetLastError());
+        }
+        MM_HIP(hipMemcpyAsync(dist.data(), ix->dist_all.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipStreamSynchronize(st));
+        std::priority_queue<Ent> heap;  // max-heap: top = the worst of the best kk so far, by (distance, row)
+        for (int64_t r = 0; r < N; ++r) {
+            const float d = dist[(size_t)r];
+            if (d != d) continue;
+            if ((int)heap.size() < kk) heap.push(Ent(d, (int32_t)r));
+            else if (Ent(d, (int32_t)r) < heap.top()) { heap.pop(); heap.push(Ent(d, (int32_t)r)); }
+        }
+        std::fill(cand.begin(), cand.end(), -1);
+        for (size_t i = 0; !heap.empty(); ++i) { cand[i] = heap.top().second; heap.pop(); }
+        MM_HIP(hipMemcpyAsync(ix->cand2.p, cand.data(), (size_t)kkpad * 4, hipMemcpyHostToDevice, st));
+        MM_HIP(hipMemcpyAsync(ix->qmap.p, &q, 4, hipMemcpyHostToDevice, st));
+        RerankArgs r{};
+        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand2.as<int32_t>();
+        r.cand_stride = kkpad; r.ncand = kkpad; r.group_mode = 0; r.nrows = N;
+        r.labels = ix->labels_d.as<int64_t>(); r.k = k;
+        r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
+        r.qmap = ix->qmap.as<int32_t>();
+        MM_TRY(launch_rerank(ix, st, r, 1));
+        MM_HIP(hipStreamSynchronize(st));  // `q` and `cand` are reused by the next query
+        ix->stat_exhaustive += 1;
+    }
+    return MMISS_OK;
+}
+
 // the widen pass for the queries listed in `which` (original indices); results overwrite their rows of d_lab / d_dist / d_cnt
 int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& which, int k, int64_t* d_lab, float* d_dist,
                   int32_t* d_cnt) {
@@ -503,7 +559,18 @@ int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
         MM_TRY(read_nflag(ix, st, &left));
         ix->stat_rounds += 1;
         if (left == 0) return MMISS_OK;
-        if (round >= 48) MM_FAIL(MMISS_ERR_STATE, "mmiss_index_query: widen pass did not converge (%d queries left)", left);
+        if (round >= mmiss_option("widen_rounds", 3)) {
+            // Still unproven after a few rounds: a plateau — more rows within eps of the k-th score than paging can walk in
+            // reasonable time (32 rows per full-index scan). Those queries get the exhaustive canonical pass instead: exact
+            // for any data, one index pass + one host selection per query. (It used to fail after ~175 000 tied rows.)
+            std::vector<int32_t> fl((size_t)Qf);
+            MM_HIP(hipMemcpyAsync(fl.data(), ix->flags.p, (size_t)Qf * 4, hipMemcpyDeviceToHost, st));
+            MM_HIP(hipStreamSynchronize(st));
+            std::vector<int32_t> rest;
+            for (int b = 0; b < Qf; ++b)
+                if (fl[b]) rest.push_back(which[b]);
+            return exhaustive_queries(ix, st, rest, k, d_lab, d_dist, d_cnt);
+        }
         pages *= 2;
     }
 }
@@ -754,6 +821,15 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         MM_HIP(hipEventRecord(ix->done_ev, st));
         ix->async_pending = true;
     }
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_index_guard_stats_ex(mmiss_index* ix, int64_t out[8]) {
+    if (!ix || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_guard_stats_ex: null argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    out[0] = ix->stat_queries; out[1] = ix->stat_flagged; out[2] = ix->stat_rounds; out[3] = ix->stat_pages;
+    out[4] = ix->stat_exhaustive;
     return MMISS_OK;
 }
 

@@ -441,10 +441,10 @@ static int launch_gemm256p(hipStream_t st, int epi, const void* A, const void* W
     const bool fold = epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16;
     if (!ep.out || !ep.bias || (fold && (!ep.ln_stats || !ep.aux || ep.ln_parts * 64 != K)))
         MM_FAIL(MMISS_ERR_ARG, "gemm256p: missing operand (fold=%d parts=%d)", (int)fold, ep.ln_parts);
-    static const char* names[] = {"", "gemm_bf16_bias", "gemm_bf16_bias_qgelu"};
+    static const char* names[] = {"", "gemm_bf16_bias_p256", "gemm_bf16_bias_qgelu_p256"};
     const int mv = ep.m_valid < M ? ep.m_valid : M;
     const double bytes = 2.0 * ((double)mv * K + (double)N * K) + 2.0 * (double)mv * N;
-    MM_PROF(fold ? (epi == MMISS_EPI_LNFOLD_BF16 ? "gemm_bf16_lnfold_bias" : "gemm_bf16_lnfold_qgelu") : names[epi], st,
+    MM_PROF(fold ? (epi == MMISS_EPI_LNFOLD_BF16 ? "gemm_bf16_lnfold_bias_p256" : "gemm_bf16_lnfold_qgelu_p256") : names[epi], st,
             gemm_flops(mv, N, K), bytes);
     switch (epi) {
         case MMISS_EPI_BIAS_BF16: return launch_gemm256p_inst<MMISS_EPI_BIAS_BF16, 0>(st, A, W, ep, M, N, K);

@@ -742,6 +742,53 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K11 last resort: the canonical distance of EVERY row to one query, dist[r] = (float)(1.0 - canon_dot(qn, row r)) — the
+// arithmetic of rerank_kernel (four rows per wave, 16 lanes per row, same additions in the same order: same bits). The
+// widen pass falls back on it when a query is still unproven after a few rounds (a plateau of hundreds of thousands of
+// rows within eps of the k-th score: identical placeholder images, re-uploads); the host then selects by (dist, row).
+// One pass over the index per query: N * D * elt bytes.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void canonical_scan_kernel(const void* __restrict__ rows, int64_t N, int D,
+                                                             const float* __restrict__ qv, float* __restrict__ dist) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p16 = lane & 15, sub = lane >> 4;
+    const float* qp = qv + 4 * p16;
+    for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 4; r0 < N; r0 += (int64_t)gridDim.x * 16) {
+        const int64_t row = r0 + sub;
+        const bool live = row < N;
+        const T* rv = reinterpret_cast<const T*>(rows) + (size_t)(live ? row : 0) * D + 4 * p16;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int d0 = 0; d0 < D; d0 += 64) {
+            const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + d0);
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (sizeof(T) == 2) {
+                u32x2 w = u32x2{0u, 0u};
+                if (live) w = *reinterpret_cast<const u32x2*>(rv + d0);
+                const _Float16* h = reinterpret_cast<const _Float16*>(&w);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rr[j] = (float)h[j];
+            } else {
+                f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (live) w = *reinterpret_cast<const f32x4*>(rv + d0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rr[j] = w[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (double)qq[j] * (double)rr[j];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __shfl_xor(acc[j], o);
+        }
+        const double t0 = acc[0] + acc[2], t1 = acc[1] + acc[3];
+        const double dot = t0 + t1;
+        if (p16 == 0 && live) dist[row] = (float)(1.0 - dot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K12: multimodal blend (backend/app/main.py:852-860), one wave per query:
 //   i^ = i/|i|, t^ = t/|t| (canonical fp64 norms, rounded to f32 like the index rows),
 //   c = (float)w * i^ + (float)(1-w) * t^   (two f32 multiplies and one f32 add, as numpy evaluates it),

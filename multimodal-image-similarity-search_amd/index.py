@@ -125,10 +125,11 @@ class FlatIndex:
 
     def guard_stats(self) -> dict:
         """Exactness accounting (mmiss_index_guard_stats): queries served, queries whose first pass could not be proven
-        exact and were widened, widen rounds, extra scan pages."""
-        out = (C.c_int64 * 4)()
-        _lib.check(self._lib.mmiss_index_guard_stats(self._h, out))
-        return {"queries": out[0], "widened": out[1], "rounds": out[2], "pages": out[3]}
+        exact and were widened, widen rounds, extra scan pages, and the queries that ended in the exhaustive canonical pass
+        (a tie plateau too long to page through)."""
+        out = (C.c_int64 * 8)()
+        _lib.check(self._lib.mmiss_index_guard_stats_ex(self._h, out))
+        return {"queries": out[0], "widened": out[1], "rounds": out[2], "pages": out[3], "exhaustive": out[4]}
 
     # ------------------------------------------------------------------ persistence
     def save(self, path: str) -> None:

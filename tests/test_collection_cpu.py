@@ -117,3 +117,30 @@ def test_mutations_are_journaled_not_resnapshotted(colmod, tmp_path):
     fourth = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
     assert fourth.count() == 38 + 4200
     assert fourth.query(query_embeddings=big[17:18], n_results=1)["ids"] == [["b17"]]
+
+
+@pytest.mark.parametrize("tail", ['{"op": "add", "ids": ["img_x"], "meta', '{"op": "delete", "ids": ["img_3"]}'])
+def test_mutations_after_a_torn_journal_tail_survive_the_next_restart(colmod, tmp_path, tail):
+    """replay used to stop at a torn last line but leave its bytes in the file; the next acknowledged mutation
+    was then glued to them, unparsable, and lost (with everything after it) at the following restart. Now the journal is cut
+    back to the last committed record before new writes are accepted. Second case: a complete record whose newline was
+    cut off counts as committed and gets its newline back."""
+    client = colmod.PersistentClient(path=str(tmp_path))
+    col = client.create_collection("image-match", metadata={"hnsw:space": "cosine"})
+    v = _vecs(12, seed=11)
+    for i in range(5):
+        col.add(ids=[f"img_{i}"], embeddings=[v[i].tolist()], metadatas=[{"n": i}])
+    jl = tmp_path / f"image-match.journal.{col._index_gen}.jsonl"
+    with open(jl, "a") as f:
+        f.write(tail)                                    # crash in the middle of (or right behind) the next append
+    committed = 5 if tail.endswith("meta") else 4        # (the complete delete record is a committed mutation)
+    second = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert second.count() == committed
+    assert open(jl, "rb").read().endswith(b"}\n")        # the file ends behind a committed record again
+    for i in range(5, 10):
+        second.add(ids=[f"img_{i}"], embeddings=[v[i].tolist()], metadatas=[{"n": i}])
+    assert second.count() == committed + 5
+    third = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert third.count() == committed + 5                # (was 5: the five acknowledged adds were lost)
+    assert third.get(ids=["img_9"])["metadatas"] == [{"n": 9}]
+    assert third.query(query_embeddings=v[7:8], n_results=1)["ids"] == [["img_7"]]

@@ -195,3 +195,33 @@ def test_filtered_selection_overflow_is_handed_to_the_widen_pass(mods):
         np.testing.assert_array_equal(l2, full[0])
         np.testing.assert_array_equal(d2.view(np.uint32), full[1].view(np.uint32))
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_a_plateau_of_250k_duplicates_ends_in_the_exhaustive_pass(mods, dtype):
+    """ADVICE r2: more rows within eps of the k-th score than the widen pass can page through (32 rows per full-index scan;
+    it used to give up with MMISS_ERR_STATE after ~175 000): 250 000 byte-identical rows (a placeholder image uploaded over
+    and over) among 300 000. The query must come back — the oracle's ids (the k smallest labels of the plateau) and distance
+    bits — through the exhaustive canonical pass, for the query on the plateau AND for its neighbours in the same batch."""
+    FlatIndex, ro, _ = mods
+    N, D = 300_000, 128
+    c = _randn(N, D, seed=900)
+    rng = np.random.Generator(np.random.Philox(901))
+    dup = np.sort(rng.choice(N, size=250_000, replace=False))
+    c[dup] = c[dup[0]]
+    labels = np.arange(N, dtype=np.int64) * 2 + 1
+    idx = FlatIndex(D, dtype)
+    idx.add(c, labels)
+    stored = ro.normalize_rows(c, dtype)
+    q = np.concatenate([c[dup[0]][None], _randn(3, D, seed=902)])
+    for k in (10, 100):
+        before = idx.guard_stats()
+        lab, dist, cnt = idx.query(q, k)
+        after = idx.guard_stats()
+        np.testing.assert_array_equal(lab[0], labels[dup[:k]])
+        assert after["exhaustive"] - before["exhaustive"] >= 1, (before, after)
+        ol, od, oc = ro.query(q, stored, labels, k)
+        np.testing.assert_array_equal(cnt, oc)
+        np.testing.assert_array_equal(lab, ol)
+        np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+    idx.close()

@@ -62,7 +62,7 @@ def test_b32_bs256_default_path_is_the_folded_one_and_matches_the_oracle(b32_256
     px[77] = px[77] * 3.0 - 2.5
     px[200] = np.abs(px[200]) * 2.0
     out, kern = _kernels_of(lambda: enc.encode_image(px))
-    assert kern.get("gemm_bf16_lnfold_bias", 0) == 12 and kern.get("gemm_bf16_lnfold_qgelu", 0) == 11, kern
+    assert kern.get("gemm_bf16_lnfold_bias_p256", 0) == 12 and kern.get("gemm_bf16_lnfold_qgelu_p256", 0) == 11, kern
     assert "layernorm" in kern and kern["layernorm"] <= 3, kern   # pre-LN, pruned last layer's LN2, head: no per-layer LN pass
     sub = np.concatenate([[5, 77, 200], np.arange(0, 256, 13)])[:24]
     ref = co.embed_images(px[sub], W, s)
@@ -71,7 +71,7 @@ def test_b32_bs256_default_path_is_the_folded_one_and_matches_the_oracle(b32_256
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
     # the same images 16 at a time: <= 800 rows per call -> ln_mode 0
     parts, kern16 = _kernels_of(lambda: np.concatenate([small.encode_image(px[i:i + 16]) for i in range(0, 256, 16)]))
-    assert "gemm_bf16_lnfold_bias" not in kern16, kern16
+    assert "gemm_bf16_lnfold_bias" not in kern16 and "gemm_bf16_lnfold_bias_p256" not in kern16, kern16
     assert (1 - _cos(parts, out)).max() < 2e-4  # two bf16 roundings of the same fp32 function (f32 residual stream at 16 rows,
     # bf16 stream at 256: measured ~6e-5)
     again = enc.encode_image(px)
@@ -95,7 +95,7 @@ def test_b32_bs256_outlier_hidden_channels(b32_256):
     rng = np.random.Generator(np.random.Philox(4321))
     px = rng.standard_normal((256, 3, 224, 224), dtype=np.float32)
     out, kern = _kernels_of(lambda: enc.encode_image(px))
-    assert kern.get("gemm_bf16_lnfold_bias", 0) == 12, kern
+    assert kern.get("gemm_bf16_lnfold_bias_p256", 0) == 12, kern
     sub = np.arange(3, 256, 32)
     d = 1 - _cos(out[sub], co.embed_images(px[sub], W, s))
     assert d.max() < COS_TOL, d
@@ -110,7 +110,7 @@ def test_b32_text_tower_256x77_default_path(b32_256):
     ids[0, 76] = s.eos_token_id
     ids[0, 1:76] = np.minimum(ids[0, 1:76], s.eos_token_id - 2)   # one prompt fills the whole context (no trimming)
     out, kern = _kernels_of(lambda: enc.encode_text(ids))
-    assert kern.get("gemm_bf16_lnfold_bias", 0) == 12, kern
+    assert kern.get("gemm_bf16_lnfold_bias_p256", 0) == 12, kern
     sub = np.arange(0, 256, 16)
     d = 1 - _cos(out[sub], co.embed_texts(ids[sub], W, s))
     assert d.max() < COS_TOL, d
@@ -255,14 +255,22 @@ def test_b32_bs256_fold_epilogue_on_the_256_tile(b32_256):
     rng = np.random.Generator(np.random.Philox(77))
     px = rng.standard_normal((256, 3, 224, 224), dtype=np.float32)
     px[9] = px[9] * 0.05 + 4.0
-    base = enc.encode_image(px)
+    base, kern_p = _kernels_of(lambda: enc.encode_image(px))   # default: the persistent 256 x 256 kernel (gemm_bf16_p256.h)
+    assert kern_p.get("gemm_bf16_lnfold_bias_p256", 0) == 12 and kern_p.get("gemm_bf16_lnfold_qgelu_p256", 0) == 11, kern_p
+    _lib.set_option("gemm_p256", 0)
     _lib.set_option("gemm_256_fold", 2304)
     _lib.set_option("gemm_256_fold_mlp", 1)
     try:
         out, kern = _kernels_of(lambda: enc.encode_image(px))
-    finally:
         _lib.set_option("gemm_256_fold", 0)
         _lib.set_option("gemm_256_fold_mlp", 0)
+        out128, kern128 = _kernels_of(lambda: enc.encode_image(px))    # ... and the 128-column tiles of rounds 1-2
+    finally:
+        _lib.set_option("gemm_p256", 1)
+        _lib.set_option("gemm_256_fold", -1)
+        _lib.set_option("gemm_256_fold_mlp", 0)
+    assert kern128.get("gemm_bf16_lnfold_bias", 0) == 12 and kern128.get("gemm_bf16_lnfold_qgelu", 0) == 11, kern128
+    assert (1 - _cos(out128, base)).max() < 5e-5
     assert kern.get("gemm_bf16_lnfold_bias", 0) == 12 and kern.get("gemm_bf16_lnfold_qgelu", 0) == 11, kern
     sub = np.concatenate([[9], np.arange(0, 256, 17)])
     assert (1 - _cos(out[sub], co.embed_images(px[sub], W, s))).max() < COS_TOL
@@ -333,3 +341,52 @@ def test_l14_full_depth_bf16_residual_stream_in_the_separate_layernorm_mode():
           % (d16, d32, d8))
     assert d16 < 3e-4 and d32 < 3e-5, (d16, d32)   # (bar: COS_TOL = 1e-3; CPU simulation 3-8e-5 / 2-3e-6)
     assert d8 < 1e-3, d8
+
+
+def test_config1_100k_distinct_images_ingested_then_queried_back(b32_256):
+    """BASELINE configs[1] as SURVEY 8(d) defines it (the reference's ingest-then-query flow, backend/app/main.py:1124-1162 ->
+    :761-765): 100 000 DISTINCT images — pixels N(0,1) generated on the device in 391 batches of 256 from seed 1234 + batch —
+    encoded at bs 256, every embedding added to the index, every embedding queried back top-10. Every row must rank itself
+    first; a 64-query subset must carry the C oracle's ids and distance bits (f16 rows, the bench's index type, and f32)."""
+    import torch
+    from mmiss_amd.index import FlatIndex
+    from oracle import retrieval_oracle_c as roc
+
+    enc, _, W, co = b32_256
+    N, D, B = 100_000, 512, 256
+    emb = torch.empty((N, D), dtype=torch.float32, device="cuda")
+    for c in range((N + B - 1) // B):
+        n = min(B, N - c * B)
+        g = torch.Generator(device="cuda").manual_seed(1234 + c)
+        px = torch.randn(B, 3, 224, 224, device="cuda", generator=g)
+        enc.encode_image(px[:n], out=emb[c * B:c * B + n])
+    torch.cuda.synchronize()
+    host = emb.cpu().numpy()
+    assert np.isfinite(host).all() and np.abs(np.linalg.norm(host, axis=1) - 1).max() < 1e-5
+    # two batches against the fp32 oracle (first and last: the 160-image tail batch takes other tile shapes)
+    for c, rows in ((0, [0, 100, 255]), (390, [0, 159])):
+        g = torch.Generator(device="cuda").manual_seed(1234 + c)
+        px = torch.randn(B, 3, 224, 224, device="cuda", generator=g).cpu().numpy()
+        ref = co.embed_images(px[rows], W, co.VIT_B32)
+        assert (1 - _cos(host[[c * B + r for r in rows]], ref)).max() < COS_TOL
+    labels = np.arange(N, dtype=np.int64)
+    sub = np.arange(0, N, N // 64)[:64]
+    for dtype, self_tol in (("f16", 1e-4), ("f32", 1e-6)):   # (f16 rows: the storage rounding puts a row ~2e-5 from itself)
+        idx = FlatIndex(D, dtype, capacity=N)
+        idx.add(emb, labels)
+        lab = np.empty((N, 10), dtype=np.int64)
+        dist = np.empty((N, 10), dtype=np.float32)
+        for i in range(0, N, 1024):
+            l, d, c = idx.query(emb[i:i + 1024], 10)
+            lab[i:i + 1024], dist[i:i + 1024] = l.cpu().numpy(), d.cpu().numpy()
+            assert (c.cpu().numpy() == 10).all()
+        gap = dist[:, 1] - dist[:, 0]
+        print(f"config 1, {dtype} rows: self-distance max {dist[:, 0].max():.2e}, smallest gap to the runner-up {gap.min():.2e}, "
+              f"guard stats {idx.guard_stats()}")
+        stored = roc.normalize_rows(host, dtype)
+        ol, od, oc = roc.query(host[sub], stored, labels, 10)
+        np.testing.assert_array_equal(lab[sub], ol)
+        np.testing.assert_array_equal(dist[sub].view(np.uint32), od.view(np.uint32))
+        assert (lab[:, 0] == labels).all(), np.nonzero(lab[:, 0] != labels)[0][:10]
+        assert dist[:, 0].max() < self_tol and (np.diff(dist, axis=1) >= 0).all()
+        idx.close()
