@@ -383,27 +383,37 @@ __global__ __launch_bounds__(64 * NWN * NWM, (NWN == 2 && NWM == 2 && !S3) ? 2 :
     // holds global chunk p ^ (r & 7)
     const int r_in = lane >> 3, p = lane & 7;
     const int src_chunk = (p ^ r_in) * 8;  // elements
+    // LDS-DMA in buffer form (round 3): the per-lane part of a piece's address — row r_in of the piece, swizzled chunk — is
+    // ONE 32-bit register computed once; piece, K-tile and tile go into the scalar offset. The flat form spent three 64-bit
+    // VALU adds and a register pair per piece.
+    const int lane_vo = (r_in * K + src_chunk) * (int)sizeof(IN);
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN*>(Ab), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN*>(Wb), 0, 0x7fffffff, 0x00020000);
+    const int row8 = 8 * K * (int)sizeof(IN);
+    auto blds16 = [&](const __amdgpu_buffer_rsrc_t& srd, int so, char* dst) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)dst, 16, lane_vo, so, 0, 0);
+    };
     auto stage = [&](int buf, int kt) {
         char* sA = smem + buf * BUF;
         char* sW = sA + A_BYTES;
-        const size_t koff = (size_t)kt * GEMM_BK + src_chunk;
+        const int koff = kt * GEMM_BK * (int)sizeof(IN);
         if constexpr (!ALN && NWN == 2 && NWM == 2) {
 #pragma unroll
             for (int i = 0; i < BM / 32; ++i) {
                 const int rowblk = wave * (BM / 32) + i;
-                glds16(Ab + (size_t)(rowblk * 8 + r_in) * K + koff, sA + rowblk * 1024);
+                blds16(srdA, rowblk * row8 + koff, sA + rowblk * 1024);
             }
         } else if constexpr (!ALN) {
 #pragma unroll
             for (int i = 0; i < (BM / 8 + NWAVES - 1) / NWAVES; ++i) {
                 const int rowblk = wave + i * NWAVES;  // BM/8 row blocks dealt round-robin to the 8 waves
-                if (rowblk < BM / 8) glds16(Ab + (size_t)(rowblk * 8 + r_in) * K + koff, sA + rowblk * 1024);
+                if (rowblk < BM / 8) blds16(srdA, rowblk * row8 + koff, sA + rowblk * 1024);
             }
         }
 #pragma unroll
         for (int i = 0; i < BN / 8 / NWAVES; ++i) {
             const int rowblk = wave * (BN / 8 / NWAVES) + i;
-            glds16(Wb + (size_t)(rowblk * 8 + r_in) * K + koff, sW + rowblk * 1024);
+            blds16(srdW, rowblk * row8 + koff, sW + rowblk * 1024);
         }
     };
 

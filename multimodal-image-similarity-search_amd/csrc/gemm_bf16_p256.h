@@ -24,14 +24,16 @@
 //   * the epilogue's stores and those pieces count in vmcnt (in issue order), so the four counted waits that follow an
 //     epilogue allow EX more operations in flight; from the fifth wait on every such operation is older than the slot
 //     being waited for and the plain count applies again;
-//   * tile order: XCD x (blockIdx % 8) works on 32 logically consecutive tiles per round, 8 row blocks x 4 column tiles
-//     in the banded order of tile_order(); the tiles of the last, partial round are dealt round-robin over the XCDs.
+//   * tile order: rounds of 256 tiles of a banded global order, 32 logically consecutive tiles (8 row blocks x 4 column
+//     tiles) per XCD; a last round of at most 128 tiles is dealt in half tiles so that every CU takes part in it.
 #pragma once
+#include <type_traits>
 #include "gemm_bf16_256.h"
 
 #define P256_BC (8 * G256_SLOT)       // 2 x 2 KB: bias [256] f32 + c [256] f32 of the current / next tile
 #define P256_TABLE (P256_BC + 4096)   // 256 x (mean, rstd)
-#define P256_RAW (P256_TABLE + 2048)  // 256 rows x K/64 x (sum, sumsq) f32, as they lie in memory; the epilogue's patches
+#define P256_TILES (P256_TABLE + 2048)  // this workgroup's tile list: 64 x (bm | bn << 16), decoded once before the K stream
+#define P256_RAW (P256_TILES + 256)    // 256 rows x K/64 x (sum, sumsq) f32, as they lie in memory; the epilogue's patches
 
 // DBG (timing experiments only, EXPERIMENTS builds, tools/gemm_p256_ablate.py; results are wrong by construction), a
 // compile-time mask: 1 = no MFMAs, 2 = no staging inside the loop, 4 = no fragment reads, 8 = every tile loads tile (0, 0)
@@ -56,17 +58,40 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     const int nbm = M >> 8, nbn = N >> 8;
     const int nt = K / GEMM_BK;  // even (K % 128 == 0)
 
-    // ---- this workgroup's tile list: ordinal i -> logical tile -> (bm, bn)
+    // ---- this workgroup's tile list. Tiles are dealt in rounds of G (256): in round i workgroup pb (its position among the
+    // workgroups of its XCD first, xcd_remap) takes tile i * G + pb of one banded global order (bands of 8 row blocks x all
+    // column tiles, m fastest inside a band: an XCD's 32 tiles of a round are 8 row blocks x 4 column tiles). A LAST round of
+    // at most G/2 tiles is dealt in HALVES — the m0 rows (wm * 128 + 0..63) and the m1 rows (+64) of a tile go to neighbouring
+    // workgroups: FC1 at 12 800 rows has 600 tiles = 2 rounds + 88, i.e. 3 tile times for 2.34 tiles of work per CU; as
+    // 176 half tiles the tail costs ~0.65 of a tile time (a half tile runs phases 0 and 1 of every K-tile with MFMAs and
+    // keeps the other two for their staging, waits and barriers only).
+    // (Per-XCD row-block ranges, with A panels meant to stay in the L2 across an XCD's rounds, measured the same time and the
+    // same fabric reads — FETCH_SIZE x 2 = 120 MB per FC1 launch: one round streams 4.6 MB of distinct operand bytes through
+    // the XCD's 4 MB L2 — and cannot balance a tail; profiles/gemm_p256_r03.txt.)
     const int T = nbm * nbn, G = gridDim.x;
-    const bool xs = (G & 7) == 0 && T >= G;
-    const int full = xs ? T / G : 0, rem = T - full * G;
-    const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
-    const int mine = xs ? full + ((bj * 8 + bx) < rem ? 1 : 0) : 1;
-    auto tile_of = [&](int i, int& bm, int& bn) {
-        int L;
-        if (xs) L = (i < full) ? i * G + bx * (G >> 3) + bj : full * G + bj * 8 + bx;
-        else L = xcd_remap(blockIdx.x, T);
-        tile_order(L, nbm, nbn, ep.m_fast, bm, bn);
+    const int pb = xcd_remap(blockIdx.x, G);
+    const int full_rounds = T / G, rem = T - full_rounds * G;
+    const bool halves = full_rounds >= 1 && rem > 0 && 2 * rem <= G;
+    const int nfull = full_rounds + ((!halves && pb < rem) ? 1 : 0);       // whole tiles of this workgroup
+    const int nhalf = (halves && pb < 2 * rem) ? 1 : 0;                    // + at most one half tile, always last
+    const int mine = nfull + nhalf;
+    // table entry: bm | bn << 16 | half tile << 30 | which half << 31
+    if (tid < mine && tid < 64) {
+        const bool hf = tid >= nfull;
+        const int L = hf ? full_rounds * G + (pb >> 1) : tid * G + pb;
+        int bm_, bn_;
+        tile_order(L, nbm, nbn, ep.m_fast, bm_, bn_);
+        reinterpret_cast<unsigned*>(smem + P256_TILES)[tid] = (unsigned)bm_ | ((unsigned)bn_ << 16) | (hf ? (1u << 30) : 0u) |
+                                                             ((hf && (pb & 1)) ? (1u << 31) : 0u);
+    }
+    __syncthreads();
+    // (decoded ONCE, in parallel, into LDS: the integer divisions are VALU code on this target, and inlined at the places of
+    // the unrolled K loop that move on to a next tile they pushed the kernel over its 256 registers: 233 spilled, 6 x slower)
+    auto tile_of = [&](int i, int& bm, int& bn, int& half) {  // half: 0 whole tile, 1 / 2 = its m0 / m1 rows only
+        const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane(reinterpret_cast<const volatile int*>(smem + P256_TILES)[i]);
+        bm = pk & 0xffff;
+        bn = (pk >> 16) & 0x3fff;
+        half = (pk >> 30) ? 1 + (int)(pk >> 31) : 0;
     };
 
     // ---- LDS-DMA sources, buffer form (one descriptor per operand): per-lane byte offset of the lane's row / chunk, computed
@@ -86,13 +111,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
 #define P256_SLOT(which, b) (((which) * 2 + (b)) * G256_SLOT)
 #define P256_BLDS(srd, vo, so, dst) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 16, vo, so, 0, 0)
-#define P256_STAGE(which, b, oA, oW)                                                                         \
+#define P256_BLDS4(srd, vo, so, dst) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 4, vo, so, 0, 0)
+// LIVE = false: the slot is not read (the A m1 slot of a half tile): its two pieces shrink to 4 bytes per lane — the K
+// stream is bound by LDS-DMA bytes per CU (64 KB per K-tile at ~40 GB/s), the operation COUNT must stay what the waits assume
+#define P256_STAGE(which, b, oA, oW, LIVE)                                                                   \
     if constexpr (!((DBG & 2) != 0)) {                                                                      \
         char* dst_ = smem + P256_SLOT(which, b) + stage_dst;                                                \
         if constexpr ((which) < 2) {                                                                        \
-            const int so_ = (oA) + ((which) & 1) * 8 * row8;                                                \
-            P256_BLDS(srdA, a_vo, so_, dst_);                                                               \
-            P256_BLDS(srdA, a_vo, so_ + row8, dst_ + 1024);                                                 \
+            const int so_ = (oA);                                                                           \
+            if (LIVE) {                                                                                     \
+                P256_BLDS(srdA, a_vo, so_, dst_);                                                           \
+                P256_BLDS(srdA, a_vo, so_ + row8, dst_ + 1024);                                             \
+            } else {                                                                                        \
+                P256_BLDS4(srdA, a_vo, so_, dst_);                                                          \
+                P256_BLDS4(srdA, a_vo, so_ + row8, dst_ + 1024);                                            \
+            }                                                                                               \
         } else {                                                                                            \
             const int so_ = (oW) + ((which) & 1) * 4 * row8;                                                \
             P256_BLDS(srdW, w_vo, so_, dst_);                                                               \
@@ -166,52 +200,57 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     }
 // The slots the LATE half (wm = 1) reads in a phase are restaged by the early half right after the next barrier: its reads
 // must have completed before that barrier (the early half's own reads complete a whole barrier earlier, with its MFMAs).
+#ifdef P256_NO_LATE_WAIT   // (A/B experiment only: without it the restage-after-read order holds by timing, not by construction)
+#define P256_LATE_READS_DONE()
+#else
 #define P256_LATE_READS_DONE() \
     if (wm == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
 // One K-tile out of buffer B: four phases [reads + one slot's staging + wait] B [16 MFMAs] B. The wait that retires a slot
 // sits in the read part of the phase BEFORE the one that reads it (both halves' waits and a barrier precede both halves'
 // reads); a slot is restaged in the phase AFTER its last read. P0 / P1 / P3 = post-epilogue form of the three waits; FIN =
 // this is K-tile 2 of a tile (the raw statistics landed behind the waits of K-tile 1).
-#define P256_KTILE(B, P0, P1, P3, FIN)                                                                       \
+#define P256_KTILE(B, P0, P1, P3, FIN, HALF)                                                                       \
     {                                                                                                       \
         P256_READ_A(B, 0);                                                                                  \
         P256_READ_W(B, 0);                                                                                  \
-        P256_STAGE(1, (B) ^ 1, oA1, oW1); /* A m1 of K-tile t+1 */                                          \
+        P256_STAGE(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0); /* A m1 of K-tile t+1 */                                          \
         P256_LATE_READS_DONE();                                                                             \
         P256_WAIT(P0);                    /* retires W n1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
         P256_MMA(0, 0);                                                                                     \
         P256_BARRIER();                                                                                     \
         P256_READ_W(B, 1);                                                                                  \
-        P256_STAGE(0, B, oA2, oW2);       /* A m0 of K-tile t+2 */                                          \
+        P256_STAGE(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                          \
         P256_LATE_READS_DONE();                                                                             \
         P256_WAIT(P1);                    /* retires A m1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
         P256_MMA(0, 1);                                                                                     \
         P256_BARRIER();                                                                                     \
-        P256_READ_A(B, 1);                                                                                  \
-        P256_STAGE(2, B, oA2, oW2);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
+        if constexpr (!(HALF)) P256_READ_A(B, 1);                                                           \
+        P256_STAGE(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
         P256_LATE_READS_DONE();                                                                             \
         P256_BARRIER();                                                                                     \
-        P256_MMA(1, 1);                                                                                     \
+        if constexpr (!(HALF)) P256_MMA(1, 1);                                                              \
         P256_BARRIER();                                                                                     \
-        P256_STAGE(3, B, oA2, oW2);       /* W n1 of K-tile t+2 */                                          \
+        P256_STAGE(3, B, oA2, oW2, true);       /* W n1 of K-tile t+2 */                                          \
         if constexpr (FOLD && (FIN)) {                                                                      \
             if (kp == 1 && tid < 256) finalize_stats();                                                     \
         }                                                                                                   \
         P256_WAIT(P3);                    /* retires A m0 / W n0 of the next K-tile */                      \
         P256_BARRIER();                                                                                     \
-        P256_MMA(1, 0);                                                                                     \
+        if constexpr (!(HALF)) P256_MMA(1, 0);                                                              \
         P256_BARRIER();                                                                                     \
         /* position t+1 becomes the old t+2; t+2 moves on one K-tile (into the next tile, or wraps in the last one) */ \
-        oA1 = oA2; oW1 = oW2;                                                                               \
+        oA1 = oA2; oW1 = oW2; mA1 = mA2;                                                                    \
         if (++k2 == nt) {                                                                                   \
             k2 = 0;                                                                                         \
             if (o2 + 1 < mine) ++o2;                                                                        \
-            int bm_, bn_;                                                                                   \
-            tile_of(o2, bm_, bn_);                                                                          \
-            oA2 = bm_ * 256 * K * 2;                                                                        \
+            int bm_, bn_, hf_;                                                                              \
+            tile_of(o2, bm_, bn_, hf_);                                                                     \
+            oA2 = bm_ * 256 * K * 2 + (hf_ == 2 ? 8 * row8 : 0);                                            \
             oW2 = bn_ * 256 * K * 2;                                                                        \
+            mA2 = hf_ ? 0 : 8 * row8;                                                                       \
             if constexpr ((DBG & 8) != 0) { oA2 = 0; oW2 = 0; }                                             \
         } else {                                                                                            \
             oA2 += GEMM_BK * 2; oW2 += GEMM_BK * 2;                                                         \
@@ -232,11 +271,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     };
 
     // ---- stream state
-    int cbm, cbn;
-    tile_of(0, cbm, cbn);
-    int oA1 = cbm * 256 * K * 2, oW1 = cbn * 256 * K * 2;  // byte offsets of K-tile 0 of tile 0, then of position t+1
+    int cbm, cbn, chalf;
+    tile_of(0, cbm, cbn, chalf);
+    int oA1 = cbm * 256 * K * 2 + (chalf == 2 ? 8 * row8 : 0), oW1 = cbn * 256 * K * 2;  // K-tile 0 of tile 0, then position t+1
     if constexpr ((DBG & 8) != 0) { oA1 = 0; oW1 = 0; }
     int oA2 = oA1 + GEMM_BK * 2, oW2 = oW1 + GEMM_BK * 2;
+    int mA1 = chalf ? 0 : 8 * row8, mA2 = mA1;   // where a position's A m1 slot comes from (a half tile has none: m0 again)
     int o2 = 0, k2 = 1;
     const int dump_row = M - 1;  // rows >= m_valid are stored to the last pad row (the store COUNT must not depend on data)
 
@@ -247,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         P256_BLDS(srdA, a_vo, oA1, d0 + P256_SLOT(0, 0)); P256_BLDS(srdA, a_vo, oA1 + row8, d0 + P256_SLOT(0, 0) + 1024);
         P256_BLDS(srdW, w_vo, oW1, d0 + P256_SLOT(2, 0)); P256_BLDS(srdW, w_vo, oW1 + row8, d0 + P256_SLOT(2, 0) + 1024);
         P256_BLDS(srdW, w_vo, oW1 + 4 * row8, d0 + P256_SLOT(3, 0)); P256_BLDS(srdW, w_vo, oW1 + 5 * row8, d0 + P256_SLOT(3, 0) + 1024);
-        P256_BLDS(srdA, a_vo, oA1 + 8 * row8, d0 + P256_SLOT(1, 0)); P256_BLDS(srdA, a_vo, oA1 + 9 * row8, d0 + P256_SLOT(1, 0) + 1024);
+        P256_BLDS(srdA, a_vo, oA1 + mA1, d0 + P256_SLOT(1, 0)); P256_BLDS(srdA, a_vo, oA1 + mA1 + row8, d0 + P256_SLOT(1, 0) + 1024);
         P256_BLDS(srdA, a_vo, oA2, d0 + P256_SLOT(0, 1)); P256_BLDS(srdA, a_vo, oA2 + row8, d0 + P256_SLOT(0, 1) + 1024);
         P256_BLDS(srdW, w_vo, oW2, d0 + P256_SLOT(2, 1)); P256_BLDS(srdW, w_vo, oW2 + row8, d0 + P256_SLOT(2, 1) + 1024);
         P256_BLDS(srdW, w_vo, oW2 + 4 * row8, d0 + P256_SLOT(3, 1)); P256_BLDS(srdW, w_vo, oW2 + 5 * row8, d0 + P256_SLOT(3, 1) + 1024);
@@ -260,52 +300,43 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     P256_BARRIER();
     if (wm == 1) P256_BARRIER();  // the lower half runs one barrier behind from here on
 
-    const int npair = nt >> 1;
-    for (int ti = 0; ti < mine; ++ti) {
-        for (int kp = 0; kp < npair; ++kp) {
-            if (kp == 0 && ti > 0) {
-                P256_KTILE(0, true, true, true, false);
-                P256_KTILE(1, true, false, false, false);
-            } else {
-                P256_KTILE(0, false, false, false, true);
-                P256_KTILE(1, false, false, false, false);
-            }
-        }
-        // ---- tile (cbm, cbn) is complete. The upper half waits one barrier for the lower half's last MFMAs, both run the
-        // epilogue side by side (while the next tile's first K-tiles are in flight), then the lower half falls one barrier
-        // behind again.
-        if (wm == 0) P256_BARRIER();
+    // ---- epilogue of the tile (cbm, cbn) out of the accumulators, JN = 8 (whole tile) or 4 (half tile: 64 rows per wave,
+    // hrow = 0 / 64 for its m0 / m1 rows) 16-row sub-tiles per wave. Runs while the next tile's first K-tiles are in flight.
+    auto epilogue = [&](auto jn_c, int hrow, int par) {
+        constexpr int JN = decltype(jn_c)::value;
         if constexpr (!((DBG & 16) != 0)) {
         int lane_e = lane;  // (opaque here: what the epilogue derives from the lane id is not kept live through the K loop)
         asm volatile("" : "+v"(lane_e));
         const int fr = lane_e & 15, fg = lane_e >> 4;
-        const char* bc = smem + P256_BC + (ti & 1) * 2048;
+        const char* bc = smem + P256_BC + par * 2048;
         f32x4 bias[4], cvec[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bias[i] = *reinterpret_cast<const f32x4*>(bc + (wn * 64 + i * 16 + 4 * fg) * 4);
             if constexpr (FOLD) cvec[i] = *reinterpret_cast<const f32x4*>(bc + 1024 + (wn * 64 + i * 16 + 4 * fg) * 4);
         }
-        float mu[8], rs[8];
+        float mu[JN], rs[JN];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < JN; ++j) {
             mu[j] = 0.f; rs[j] = 1.f;
             if constexpr (FOLD) {
-                const float* tb = reinterpret_cast<const float*>(smem + P256_TABLE) + 2 * (wm * 128 + j * 16 + fr);
+                const float* tb = reinterpret_cast<const float*>(smem + P256_TABLE) + 2 * (wm * 128 + hrow + j * 16 + fr);
                 mu[j] = tb[0]; rs[j] = tb[1];
             }
         }
         uint16_t* outp = reinterpret_cast<uint16_t*>(ep.out);
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc(ep.out, 0, 0x7fffffff, 0x00020000);
+        const int st_pol = ep.nt_out;  // cache policy of the output stores (launch_gemm256p_inst)
         if constexpr (STYLE == 0) {
             // Each wave transposes 16 rows x 64 columns at a time through a private 2 KB patch (its own share of the raw
             // statistics area, dead since K-tile 2 and refilled by this wave only after these stores). 8-byte slot s of
-            // row r lies at slot s ^ 2 (r & 7): conflict-free both ways.
+            // row r lies at slot s ^ 2 (r & 7).
             char* patch = smem + P256_RAW + wave * (XP >= 2 ? XP * 1024 : 2048);  // = the bytes stage_x() of THIS wave refills
             const int rrow = lane_e >> 3, rchunk = lane_e & 7;
             const int wr_off = fr * 128, wr_sw = 2 * (fr & 7);
             const int col = cbn * 256 + wn * 64 + rchunk * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < JN; ++j) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float y[4];
@@ -328,16 +359,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                 for (int rh = 0; rh < 2; ++rh) {
                     const int row = rh * 8 + rrow;
                     const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((2 * rchunk) ^ (2 * (row & 7))) << 3));
-                    const int m = cbm * 256 + wm * 128 + j * 16 + row;
+                    const int m = cbm * 256 + wm * 128 + hrow + j * 16 + row;
+                    const int vo = ((m < ep.m_valid ? m : dump_row) * ep.ldo + col) * 2;
                     if constexpr ((DBG & 32) != 0) asm volatile("" ::"v"(v));
-                    else *reinterpret_cast<u32x4*>(outp + (size_t)(m < ep.m_valid ? m : dump_row) * ep.ldo + col) = v;
+                    else if (st_pol == 16) __builtin_amdgcn_raw_buffer_store_b128(v, srdO, vo, 0, 16);   // sc1: written through, dropped from L2
+                    else if (st_pol == 2) __builtin_amdgcn_raw_buffer_store_b128(v, srdO, vo, 0, 2);      // nt
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, srdO, vo, 0, 0);
                 }
                 __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next j
             }
         } else {
             const int colb = cbn * 256 + wn * 64 + (fg >> 1) * 8 + (fg & 1) * 16;  // + pair * 32
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < JN; ++j) {
                 uint32_t pk[4][2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -352,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                     pk[i][1] = pack_bf16x2(y[2], y[3]);
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                const int m = cbm * 256 + wm * 128 + j * 16 + fr;
+                const int m = cbm * 256 + wm * 128 + hrow + j * 16 + fr;
                 uint16_t* orow = outp + (size_t)(m < ep.m_valid ? m : dump_row) * ep.ldo + colb;
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
@@ -367,12 +401,46 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                 }
             }
         }
-        }  // (epilogue)
+        }  // (DBG & 16)
+    };
+
+    const int npair = nt >> 1;
+    // ---- whole tiles
+    for (int ti = 0; ti < nfull; ++ti) {
+        for (int kp = 0; kp < npair; ++kp) {
+            if (kp == 0 && ti > 0) {
+                P256_KTILE(0, true, true, true, false, false);
+                P256_KTILE(1, true, false, false, false, false);
+            } else {
+                P256_KTILE(0, false, false, false, true, false);
+                P256_KTILE(1, false, false, false, false, false);
+            }
+        }
+        // The tile is complete. The upper half waits one barrier for the lower half's last MFMAs, both run the epilogue side
+        // by side, then the lower half falls one barrier behind again.
+        if (wm == 0) P256_BARRIER();
+        epilogue(std::integral_constant<int, 8>{}, 0, ti & 1);
         if (ti + 1 < mine) {
-            tile_of(ti + 1, cbm, cbn);
+            tile_of(ti + 1, cbm, cbn, chalf);
             stage_x(cbm, cbn, (ti + 1) & 1);
             if (wm == 1) P256_BARRIER();
         }
+    }
+    // ---- the half tile of the last round, if this workgroup has one (always behind at least one whole tile: POST waits).
+    // Out of the loop above so that the upper accumulators are plainly dead here (inside it the compiler kept them alive
+    // through the half tile's K loop and spilled).
+    if (nhalf) {
+        for (int kp = 0; kp < npair; ++kp) {
+            if (kp == 0) {
+                P256_KTILE(0, true, true, true, false, true);
+                P256_KTILE(1, true, false, false, false, true);
+            } else {
+                P256_KTILE(0, false, false, false, true, true);
+                P256_KTILE(1, false, false, false, false, true);
+            }
+        }
+        if (wm == 0) P256_BARRIER();
+        epilogue(std::integral_constant<int, 4>{}, chalf == 2 ? 64 : 0, nfull & 1);
     }
     if constexpr ((DBG & 16) != 0) {  // (ablation without epilogue: keep the accumulators alive)
         f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -388,6 +456,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
 #undef P256_STAGE
 #undef P256_SLOT
 #undef P256_BLDS
+#undef P256_BLDS4
 #undef P256_READ_A
 #undef P256_READ_W
 #undef P256_MMA
@@ -411,7 +480,11 @@ static int launch_gemm256p_kern(hipStream_t st, const void* A, const void* W, co
 template <int EPI, int XP>
 static int launch_gemm256p_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep_in, int M, int N, int K) {
     GemmEpi ep = ep_in;
-    if (ep.m_fast == 0) ep.m_fast = mmiss_option("gemm_p256_band", 8);
+    if (ep.m_fast == 0) ep.m_fast = mmiss_option("gemm_p256_band", 8);  // row blocks per band of the global tile order
+    // Cache policy of the output stores: 0 plain, 2 nt, 16 sc1 (written through, not kept in the XCD's L2). Measured equal in
+    // time and in fabric reads (FETCH_SIZE x 2 = 119-126 MB per FC1 launch either way): one round of an XCD's 32 tiles streams
+    // 4.6 MB of distinct operand bytes through its 4 MB L2, so nothing survives to the next round whatever the stores do.
+    ep.nt_out = mmiss_option("gemm_p256_store", 0);
 #ifdef MMISS_EXPERIMENTS
     if constexpr (EPI == MMISS_EPI_LNFOLD_QGELU_BF16 && XP == 3) {
         const int dbg = mmiss_option("gemm_p256_dbg", 0);  // timing ablations (wrong results by construction)
@@ -430,6 +503,8 @@ static int launch_gemm256p_inst(hipStream_t st, const void* A, const void* W, co
 // statistics of a tile must fit beside the staging buffers)
 static inline bool gemm256p_ok(int epi, int M, int N, int K) {
     if (M <= 0 || (M % 256) || N <= 0 || (N % 256) || K < 256 || (K % 256)) return false;
+    if ((int64_t)(M / 256) * (N / 256) > 48 * 256 || M / 256 > 0xffff) return false;  // (tile table: 64 entries per workgroup)
+    if ((int64_t)M * N * 2 >= (1LL << 31) || (int64_t)M * K * 2 >= (1LL << 31) || (int64_t)N * K * 2 >= (1LL << 31)) return false;  // (32-bit buffer offsets)
     if (epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16) return K == 512 || K == 768;
     return epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16;
 }

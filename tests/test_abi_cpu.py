@@ -65,3 +65,26 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_persistent_gemm_kernels_do_not_spill():
+    """The persistent GEMM counts its own vector-memory operations (s_waitcnt vmcnt(N) with N = loads it leaves in flight):
+    a register spill is a scratch load / store the count does not know about — correct only by over-waiting, and measured
+    6 x slower. The build writes the compiler's per-kernel resource report next to the objects (csrc/Makefile)."""
+    import re
+
+    path = os.path.join(ROOT, "multimodal-image-similarity-search_amd", "csrc", "api_encoder.resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("no resource report: the library was not built by csrc/Makefile in this tree")
+    text = open(path).read()
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "gemm256p_kernel" not in name:
+            continue
+        seen += 1
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        assert scratch == 0 and spill == 0, (name, scratch, spill)
+    assert seen >= 6, seen

@@ -28,4 +28,10 @@ def test_bench_two_ranks_gloo_dry_run():
     assert out["unit"] == "images/s" and out["value"] > 0 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 512
     assert out["retrieval"]["rows"] == 200000 and out["retrieval"]["rows_per_gpu"] == 100000
-    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"] is None  # the CPU baseline runs at N = 1 only
+    assert out["roofline"]["frac"] > 0 and "N = 1" in out["cpu_baseline"]["see"]  # the CPU baseline runs at N = 1 only
+    d = out["distributed"]     # a SCALE line must explain itself: who ran, what was exchanged, where the step's time went
+    assert d["world_size"] == 2 and len(d["device_count_seen_by_each_rank"]) == 2 and d["queries_per_rank_and_step"] == 512
+    assert d["topk_exchange_bytes_per_rank"] == 512 * 10 * 12 and d["query_gather_bytes_per_rank"] == 256 * 512 * 4
+    st = d["stage_ms_max_over_ranks"]
+    assert set(st) == {"encode", "all_gather_queries", "local_query", "all_gather_topk", "merge"} and all(v > 0 for v in st.values())
+    assert "N-fold" in d["weak_scaling_note"]

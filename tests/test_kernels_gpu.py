@@ -421,11 +421,13 @@ def _p256(env, epi, A, W, out, bias, aux=None, stats=None, m_valid=None, eps=1e-
 
 
 @pytest.mark.parametrize("M,N,K,mv", [(512, 512, 256, 512), (2560, 2304, 768, 2560), (768, 1536, 512, 700),
-                                      (12800, 2304, 768, 12800), (12800, 3072, 768, 12750), (19712, 2048, 512, 19712)])
+                                      (12800, 2304, 768, 12800), (12800, 3072, 768, 12750), (19712, 2048, 512, 19712),
+                                      (1792, 9984, 512, 1792), (33024, 1024, 768, 32896)])
 def test_gemm_p256_persistent(env, M, N, K, mv):
     """The persistent 256 x 256 kernel (gemm_bf16_p256.h): one tile per workgroup (T < 256 tiles), 1-2 and 2-3 tiles per
     workgroup as ONE K stream (450 / 600 / 616 tiles: counted waits across the epilogue stores, LDS-DMA'd bias and
-    LayerNorm statistics, the partial last round), pad rows. Plain epilogues bit-identical to the one-tile-per-workgroup
+    LayerNorm statistics, ragged per-XCD ranges), 273 tiles over 7 row blocks (too few row blocks for the per-XCD ranges:
+    the global order), 516 tiles of a 129-row-block ViT-L/14 batch, pad rows. Plain epilogues bit-identical to the one-tile-per-workgroup
     256 x 256 kernel (same k order, same formula); folded-LayerNorm epilogues against an fp32 restatement. Repeated to
     catch a schedule race."""
     torch, _lib, lib = env

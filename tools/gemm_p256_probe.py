@@ -27,3 +27,11 @@ else:
     _lib.check(lib.mmiss_dbg_gemm_p256(0, None, epi, A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr(),
                                        cvec.data_ptr(), stats.data_ptr(), 1e-5, M, N, K, M, iters, C.byref(ms)))
 print("M %d N %d K %d epi %d: %.1f us per launch" % (M, N, K, epi, ms.value * 1e3))
+
+if os.environ.get("CALIB"):   # known byte counts under the same counters: a 256 MiB device-to-device copy (16 B per lane)
+    x = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+    y = torch.empty_like(x)
+    for _ in range(5):
+        y.copy_(x)
+    torch.cuda.synchronize()
+    print("calibration: 5 copies of %d bytes (read + write each)" % (x.numel() * 4))

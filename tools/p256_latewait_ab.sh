@@ -1,0 +1,15 @@
+set -u
+cd "$GRAFT_REPO_ROOT"
+echo "== product build"
+for i in 1 2; do
+M=4096 N=4096 K=4096 EPI=1 ITERS=20 python tools/gemm_p256_probe.py
+M=8192 N=8192 K=8192 EPI=1 ITERS=5 python tools/gemm_p256_probe.py
+python tools/gemm_p256_probe.py; EPI=7 N=2304 python tools/gemm_p256_probe.py
+done
+echo "== without the late half's lgkmcnt(0)"
+make -C multimodal-image-similarity-search_amd/csrc clean > /dev/null
+make -C multimodal-image-similarity-search_amd/csrc -j16 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -DP256_NO_LATE_WAIT" > gpurun_out/ab_build.log 2>&1 || tail -5 gpurun_out/ab_build.log
+for i in 1 2; do
+M=4096 N=4096 K=4096 EPI=1 ITERS=20 python tools/gemm_p256_probe.py
+python tools/gemm_p256_probe.py; EPI=7 N=2304 python tools/gemm_p256_probe.py
+done

@@ -21,7 +21,7 @@ import csv, glob, collections
 for f in sorted(glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
-        if "gemm256" not in r["Kernel_Name"] and "gemm16" not in r["Kernel_Name"]:
+        if "gemm256" not in r["Kernel_Name"] and "gemm16" not in r["Kernel_Name"] and "copy" not in r["Kernel_Name"].lower():
             continue
         k = (r["Kernel_Name"][:40], r["Counter_Name"])
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
