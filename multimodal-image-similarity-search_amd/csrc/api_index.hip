@@ -4,6 +4,7 @@
 #include <queue>
 #include "retrieval_kernels.h"
 #include "gemm_bf16_256.h"
+#include "gemm_bf16_p256.h"
 #include <algorithm>
 
 struct mmiss_index {
@@ -678,6 +679,8 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         GemmEpi ep{};
         ep.out = ix->gmax.p; ep.ldo = ng; ep.m_valid = Q; ep.p0 = (int)N; ep.m_fast = 1;
         int strip = 1;
+        // the strip kernel on the staggered loop of the persistent encoder GEMM (gemm_bf16_p256.h; round 3): D % 128 == 0
+        const bool strip_v3 = mmiss_option("score_strip_v3", 1) != 0 && (D % 128) == 0 && D >= 256;
         if (big) {
             // consecutive N-tiles per workgroup: long enough to amortise the pipeline fill, short enough to leave
             // >= 8 workgroups per CU for balance
@@ -689,7 +692,9 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         {
             MM_PROF(filtered ? "score_gemm_f16_sample" : "score_gemm_f16", st, 2.0 * Q * (double)std::min<int64_t>(N, Ndense) * D,
                     (double)std::min<int64_t>(N, Ndense) * D * 2);
-            if (big)
+            if (big && strip_v3)
+                MM_TRY((launch_gemm256s<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Ndense, D, strip)));
+            else if (big)
                 MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Ndense, D, strip)));
             else
                 MM_TRY((launch_gemm_inst<_Float16, 128, MMISS_EPI_GROUPMAX_F32>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D)));
@@ -733,7 +738,8 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
             flt.cap = cap; flt.bn_begin = (int)ns_tiles;
             {
                 MM_PROF("score_gemm_f16", st, 2.0 * Q * (double)(N - Ndense) * D, (double)(N - Ndense) * D * 2);
-                MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
+                if (strip_v3) MM_TRY((launch_gemm256s<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
+                else MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
             }
             m.in_s = ix->seed_s.as<float>(); m.in_r = ix->seed_r.as<int32_t>(); m.L = 1;
             m.flat_s = ix->fbuf_s.as<float>(); m.flat_r = ix->fbuf_g.as<int32_t>(); m.flat_cnt = ix->fcnt.as<int32_t>();

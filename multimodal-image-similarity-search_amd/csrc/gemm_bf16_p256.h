@@ -45,6 +45,7 @@ template <int EPI, int XP, int STYLE = 0, int DBG = 0>  // XP = 16-byte statisti
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W, int M,
                                                           int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __bf16 IN_T;
     typedef bf16x8 frag;
     constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
     constexpr bool GELU = (EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
             _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                \
                 _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                            \
-                    acc[(nq) * 2 + nf][(mq) * 4 + mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
-                        wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf], 0, 0, 0);              \
+                    acc[(nq) * 2 + nf][(mq) * 4 + mf] = MfmaIn<IN_T>::mma(                                  \
+                        wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf]);                       \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     }
 // counted wait: 10 = the five slot loads (2 pieces each) that stay in flight; POST = the stores and pieces of the
@@ -234,27 +235,32 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         if constexpr (!(HALF)) P256_MMA(1, 1);                                                              \
         P256_BARRIER();                                                                                     \
         P256_STAGE(3, B, oA2, oW2, true);       /* W n1 of K-tile t+2 */                                          \
-        if constexpr (FOLD && (FIN)) {                                                                      \
-            if (kp == 1 && tid < 256) finalize_stats();                                                     \
-        }                                                                                                   \
+        P256_FIN_HOOK(FIN);                                                                                 \
         P256_WAIT(P3);                    /* retires A m0 / W n0 of the next K-tile */                      \
         P256_BARRIER();                                                                                     \
         if constexpr (!(HALF)) P256_MMA(1, 0);                                                              \
         P256_BARRIER();                                                                                     \
-        /* position t+1 becomes the old t+2; t+2 moves on one K-tile (into the next tile, or wraps in the last one) */ \
-        oA1 = oA2; oW1 = oW2; mA1 = mA2;                                                                    \
-        if (++k2 == nt) {                                                                                   \
-            k2 = 0;                                                                                         \
-            if (o2 + 1 < mine) ++o2;                                                                        \
-            int bm_, bn_, hf_;                                                                              \
-            tile_of(o2, bm_, bn_, hf_);                                                                     \
-            oA2 = bm_ * 256 * K * 2 + (hf_ == 2 ? 8 * row8 : 0);                                            \
-            oW2 = bn_ * 256 * K * 2;                                                                        \
-            mA2 = hf_ ? 0 : 8 * row8;                                                                       \
-            if constexpr ((DBG & 8) != 0) { oA2 = 0; oW2 = 0; }                                             \
-        } else {                                                                                            \
-            oA2 += GEMM_BK * 2; oW2 += GEMM_BK * 2;                                                         \
-        }                                                                                                   \
+        P256_ADVANCE();                                                                                     \
+    }
+// (encoder GEMM) K-tile 2 of a tile makes the (mean, rstd) table of the tile's rows in its last, read-free phase
+#define P256_FIN_HOOK(FIN)                                                                                   \
+    if constexpr (FOLD && (FIN)) {                                                                          \
+        if (kp == 1 && tid < 256) finalize_stats();                                                         \
+    }
+// position t+1 becomes the old t+2; t+2 moves on one K-tile (into the next tile, or wraps in the last one)
+#define P256_ADVANCE()                                                                                       \
+    oA1 = oA2; oW1 = oW2; mA1 = mA2;                                                                        \
+    if (++k2 == nt) {                                                                                       \
+        k2 = 0;                                                                                             \
+        if (o2 + 1 < mine) ++o2;                                                                            \
+        int bm_, bn_, hf_;                                                                                  \
+        tile_of(o2, bm_, bn_, hf_);                                                                         \
+        oA2 = bm_ * 256 * K * 2 + (hf_ == 2 ? 8 * row8 : 0);                                                \
+        oW2 = bn_ * 256 * K * 2;                                                                            \
+        mA2 = hf_ ? 0 : 8 * row8;                                                                           \
+        if constexpr ((DBG & 8) != 0) { oA2 = 0; oW2 = 0; }                                                 \
+    } else {                                                                                                \
+        oA2 += GEMM_BK * 2; oW2 += GEMM_BK * 2;                                                             \
     }
 
     auto finalize_stats = [&]() {  // thread t: (mean, rstd) of the tile's row t from its K/64 partial (sum, sumsq)
@@ -453,6 +459,158 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     // the unconditional staging of the last K-tiles is still in flight: LDS must not be handed on with DMA writes pending
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#undef P256_FIN_HOOK
+#undef P256_ADVANCE
+#define P256_FIN_HOOK(FIN)
+#define P256_ADVANCE()                                                                                       \
+    oA1 = oA2; oW1 = oW2;                                                                                   \
+    if (++k2 == nt) {                                                                                       \
+        k2 = 0;                                                                                             \
+        if (o2 + 1 < mine) ++o2;                                                                            \
+        oA2 = 0; oW2 = o2 * 256 * K * (int)sizeof(IN);                                                      \
+    } else {                                                                                                \
+        oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * (int)sizeof(IN);                                 \
+    }
+
+// ------------------------------------------------------------------------------------------------
+// The retrieval score GEMM (GROUPMAX epilogue, gemm256_strip_kernel's contract: a workgroup walks `strip` consecutive
+// 256-row tiles of the index for one 256-query tile as ONE K-tile stream) on the loop of the persistent kernel above:
+// staggered wave halves, buffer-form LDS-DMA with scalar offsets, immediates for every LDS address. The epilogue is
+// registers only (16-row group maxima; dense stores or, FILTER, rare threshold-passing appends), so the counted waits never
+// have to allow for it. K = D of the index (a multiple of 128).
+// ------------------------------------------------------------------------------------------------
+template <typename IN, bool FILTER>
+__global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M, int N, int K,
+                                                          int strip, GemmEpi ep, StripFilter flt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef IN IN_T;
+    typedef typename MfmaIn<IN>::frag frag;
+    constexpr int DBG = 0;
+    constexpr bool FOLD = false;
+    constexpr int EX = 0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nbm = M >> 8, nbn = N >> 8;
+    const int nt = K / GEMM_BK;
+    const int bn_begin = FILTER ? flt.bn_begin : 0;
+    const int nstrips = (nbn - bn_begin + strip - 1) / strip;
+    const int wg = xcd_remap(blockIdx.x, nbm * nstrips);
+    const int sidx = wg / nbm, bm = wg - sidx * nbm;   // m fastest: the M-tiles of one strip run side by side
+    const int bn0 = bn_begin + sidx * strip;
+    const int mine = (nbn - bn0 < strip) ? nbn - bn0 : strip;
+    const IN* Ab = A + (size_t)bm * 256 * K;
+    const IN* Wb = W + (size_t)bn0 * 256 * K;          // offsets inside a strip fit 32 bits (strip <= 32 tiles of <= 1 MB)
+
+    const int r_in = lane >> 3, p = lane & 7;
+    const int src_chunk = (p ^ r_in) * 8;
+    const int a_vo = (((wave >> 2) * 128 + (wave & 3) * 16 + r_in) * K + src_chunk) * (int)sizeof(IN);
+    const int w_vo = (((wave >> 1) * 64 + (wave & 1) * 16 + r_in) * K + src_chunk) * (int)sizeof(IN);
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN*>(Ab), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN*>(Wb), 0, 0x7fffffff, 0x00020000);
+    const int row8 = 8 * K * (int)sizeof(IN);
+    const int stage_dst = wave * 2048;
+    const int mA1 = 8 * row8;
+    uint32_t ab[2], wb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        ab[s] = (wm * 64 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
+        wb[s] = P256_SLOT(2, 0) + (wn * 32 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
+    }
+    frag am[4][2];
+    frag wq[2][2][2];
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float tau_r[8];  // FILTER: thresholds of this lane's 8 queries, complete before the stream starts
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tau_r[j] = INFINITY;
+    if constexpr (FILTER) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = bm * 256 + wm * 128 + j * 16 + fr;
+            if (m < ep.m_valid) tau_r[j] = flt.tau[(size_t)m * flt.tau_stride];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(tau_r[j]));
+    }
+
+    int oA1 = 0, oW1 = 0, oA2 = GEMM_BK * (int)sizeof(IN), oW2 = oA2;
+    int o2 = 0, k2 = 1;
+    {
+        char* d0 = smem + stage_dst;
+        P256_BLDS(srdA, a_vo, oA1, d0 + P256_SLOT(0, 0)); P256_BLDS(srdA, a_vo, oA1 + row8, d0 + P256_SLOT(0, 0) + 1024);
+        P256_BLDS(srdW, w_vo, oW1, d0 + P256_SLOT(2, 0)); P256_BLDS(srdW, w_vo, oW1 + row8, d0 + P256_SLOT(2, 0) + 1024);
+        P256_BLDS(srdW, w_vo, oW1 + 4 * row8, d0 + P256_SLOT(3, 0)); P256_BLDS(srdW, w_vo, oW1 + 5 * row8, d0 + P256_SLOT(3, 0) + 1024);
+        P256_BLDS(srdA, a_vo, oA1 + mA1, d0 + P256_SLOT(1, 0)); P256_BLDS(srdA, a_vo, oA1 + mA1 + row8, d0 + P256_SLOT(1, 0) + 1024);
+        P256_BLDS(srdA, a_vo, oA2, d0 + P256_SLOT(0, 1)); P256_BLDS(srdA, a_vo, oA2 + row8, d0 + P256_SLOT(0, 1) + 1024);
+        P256_BLDS(srdW, w_vo, oW2, d0 + P256_SLOT(2, 1)); P256_BLDS(srdW, w_vo, oW2 + row8, d0 + P256_SLOT(2, 1) + 1024);
+        P256_BLDS(srdW, w_vo, oW2 + 4 * row8, d0 + P256_SLOT(3, 1)); P256_BLDS(srdW, w_vo, oW2 + 5 * row8, d0 + P256_SLOT(3, 1) + 1024);
+    }
+    oA1 = oA2; oW1 = oW2;
+    oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * (int)sizeof(IN);
+    k2 = 2;
+    P256_WAIT(false);
+    P256_BARRIER();
+    if (wm == 1) P256_BARRIER();
+
+    const int npair = nt >> 1;
+    float* out = reinterpret_cast<float*>(ep.out);
+    for (int ti = 0; ti < mine; ++ti) {
+        for (int kp = 0; kp < npair; ++kp) {
+            P256_KTILE(0, false, false, false, false, false);
+            P256_KTILE(1, false, false, false, false, false);
+        }
+        // ---- this index tile is complete: group maxima out (the group numbering of gemm256_kernel), accumulators reset.
+        // A few hundred cycles of VALU: it runs without leaving the staggered rhythm (each half does it in front of its next
+        // read part, the other half is in its MFMAs), and only the index's last tile pays for masking the pad rows.
+        const int bn = bn0 + ti;
+        const int g = (bn * 4 + wn) * 4 + fg;
+        const int n0 = bn * 256 + wn * 64 + 4 * fg;
+        const bool whole = (bn + 1) * 256 <= ep.p0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float mx = -INFINITY;
+            if (whole) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = (n0 + i * 16 + r < ep.p0) ? acc[i][j][r] : -INFINITY;
+                        mx = fmaxf(mx, v);
+                        acc[i][j][r] = 0.f;
+                    }
+            }
+            const int m = bm * 256 + wm * 128 + j * 16 + fr;
+            if constexpr (FILTER) {
+                if (mx >= tau_r[j] && mx > -INFINITY) {  // (tau_r = +inf for pad queries; -inf maxima = all-pad groups)
+                    const int pos = atomicAdd(flt.cnt + m, 1);
+                    if (pos < flt.cap) {
+                        flt.buf_s[(size_t)m * flt.cap + pos] = mx;
+                        flt.buf_g[(size_t)m * flt.cap + pos] = g;
+                    }
+                }
+            } else {
+                if (m < ep.m_valid) out[(size_t)m * ep.ldo + g] = mx;
+            }
+        }
+    }
+    if (wm == 0) P256_BARRIER();   // (the upper half's last barrier: the lower half is still one behind)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #undef P256_STAGE
 #undef P256_SLOT
 #undef P256_BLDS
@@ -463,6 +621,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
 #undef P256_WAIT
 #undef P256_BARRIER
 #undef P256_KTILE
+#undef P256_FIN_HOOK
+#undef P256_ADVANCE
 #undef P256_LATE_READS_DONE
 
 template <int EPI, int XP, int STYLE, int DBG>
@@ -531,4 +691,29 @@ static int launch_gemm256p(hipStream_t st, int epi, const void* A, const void* W
             return K == 768 ? launch_gemm256p_inst<MMISS_EPI_LNFOLD_QGELU_BF16, 3>(st, A, W, ep, M, N, K)
                             : launch_gemm256p_inst<MMISS_EPI_LNFOLD_QGELU_BF16, 2>(st, A, W, ep, M, N, K);
     }
+}
+
+// the strip score GEMM on the staggered loop (same arguments as launch_gemm256_strip; K % 128 == 0)
+template <typename IN>
+static int launch_gemm256s(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K, int strip,
+                           const StripFilter* flt = nullptr) {
+    if (M <= 0 || N <= 0 || K < 256 || (M % 256) || (N % 256) || (K % 128) || strip < 1 || strip > 32 ||
+        (int64_t)strip * 256 * K * (int64_t)sizeof(IN) >= (1LL << 31) || (int64_t)256 * K * (int64_t)sizeof(IN) >= (1LL << 31))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256s: M=%d N=%d K=%d strip=%d", M, N, K, strip);
+    const int nbn = N / 256;
+    if (flt) {
+        if (flt->bn_begin < 0 || flt->bn_begin >= nbn || !flt->tau || !flt->cnt || !flt->buf_s || !flt->buf_g || flt->cap <= 0)
+            MM_FAIL(MMISS_ERR_ARG, "gemm256s: bad filter");
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, true>), G256_LDS));
+        const int nwg = (M / 256) * ((nbn - flt->bn_begin + strip - 1) / strip);
+        hipLaunchKernelGGL((gemm256s_kernel<IN, true>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                           reinterpret_cast<const IN*>(W), M, N, K, strip, ep, *flt);
+    } else {
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, false>), G256_LDS));
+        const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
+        hipLaunchKernelGGL((gemm256s_kernel<IN, false>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                           reinterpret_cast<const IN*>(W), M, N, K, strip, ep, StripFilter{});
+    }
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
 }

@@ -48,18 +48,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
         const f32x4* st = reinterpret_cast<const f32x4*>(ep.ln_stats + (size_t)m * ep.ln_parts * 2);
         float s1 = 0.f, s2 = 0.f;
         const int n4 = ep.ln_parts >> 1;
-        for (int q0 = 0; q0 < n4; q0 += 8) {  // eight loads in flight per step (K = 768: three steps, not 24 round trips)
-            f32x4 buf[8];
+        // all of a row's partial sums in flight at once (K = 768: 24 loads, ONE round trip; in steps of 8 they were three
+        // dependent round trips, ~3 us of a 9 us kernel: rocprofv3 of one request, round 3). Same summation order.
+        for (int q0 = 0; q0 < n4; q0 += 24) {
+            f32x4 buf[24];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) buf[j] = (q0 + j < n4) ? st[q0 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 24; ++j) buf[j] = (q0 + j < n4) ? st[q0 + j] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s1 += buf[j][0] + buf[j][2]; s2 += buf[j][1] + buf[j][3]; }
+            for (int j = 0; j < 24; ++j) { s1 += buf[j][0] + buf[j][2]; s2 += buf[j][1] + buf[j][3]; }
         }
         const float kd = (float)(ep.ln_parts * 16);
         mean = s1 / kd;
         rstd = 1.0f / sqrtf(fmaxf(s2 / kd - mean * mean, 0.f) + ep.ln_eps);
     };
     float pre_mean = 0.f, pre_rstd = 1.f;
+
+    // Everything the epilogue reads from memory is requested NOW, so that it flies under the weight stream: bias / c of this
+    // lane's 4 output features, and (residual epilogues) the old residual values of the FIRST m-tile this wave finishes. Loaded
+    // where they are used they were one more dependent round trip (~1 us of a 9 us kernel) behind the K loop and the reduction.
+    const int n_pre = n0 + fg * 4;
+    constexpr bool HAS_BIAS = (EPI != MMISS_EPI_F32 && EPI != MMISS_EPI_PATCH_F32);
+    f32x4 pre_bias = f32x4{0.f, 0.f, 0.f, 0.f}, pre_cv = f32x4{0.f, 0.f, 0.f, 0.f}, pre_res = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (HAS_BIAS) pre_bias = *reinterpret_cast<const f32x4*>(ep.bias + n_pre);
+    if constexpr (FOLD) pre_cv = *reinterpret_cast<const f32x4*>(ep.aux + n_pre);
+    if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
+        const int m = m_base + wave * 16 + fr;
+        if (wave < MT && m < M) pre_res = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.out) + (size_t)m * ep.ldo + n_pre);
+    }
 
     // U k-steps per trip: every load of the trip (U weight fragments from HBM/MALL, U*MT activation fragments from L2)
     // is issued before its first MFMA - the loop is bound by memory latency, so what matters is loads in flight.
@@ -106,8 +121,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
                 // a row, fixed xor order, one writer -> deterministic. [M][N/16][2]: the next folded skinny GEMM sums them.
                 float rs = 0.f, rq = 0.f;
                 if (m < M) {
-                    const f32x4 nv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.out) + (size_t)m * ep.ldo + n) +
-                                     v + *reinterpret_cast<const f32x4*>(ep.bias + n);
+                    const f32x4 oldv = (t == wave) ? pre_res
+                                                   : *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.out) + (size_t)m * ep.ldo + n);
+                    const f32x4 nv = oldv + v + pre_bias;
                     rs = (nv[0] + nv[1]) + (nv[2] + nv[3]);
                     rq = (nv[0] * nv[0] + nv[1] * nv[1]) + (nv[2] * nv[2] + nv[3] * nv[3]);
                 }
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
         if constexpr (EPI == MMISS_EPI_F32) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n) = v;
         } else if constexpr (EPI == MMISS_EPI_BIAS_BF16 || EPI == MMISS_EPI_BIAS_QGELU_BF16) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + n);
+            const f32x4 b = pre_bias;
             float y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -141,8 +157,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
             // skinny residual GEMM (or skinny_row_stats16_kernel) left in ep.ln_stats [M][ln_parts][2], ln_parts = K / 16
             float mean = pre_mean, rstd = pre_rstd;
             if (t != wave) row_mean_rstd(m, mean, rstd);  // (more m-tiles than waves: the later ones pay the loads here)
-            const f32x4 b = *reinterpret_cast<const f32x4*>(ep.bias + n);
-            const f32x4 cv = *reinterpret_cast<const f32x4*>(ep.aux + n);
+            const f32x4 b = pre_bias;
+            const f32x4 cv = pre_cv;
             float y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -154,9 +170,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
             pk[1] = pack_bf16x2(y[2], y[3]);
             *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(ep.out) + (size_t)m * ep.ldo + n) = pk;
         } else if constexpr (EPI == MMISS_EPI_BIAS_RESID_F32) {
-            v += *reinterpret_cast<const f32x4*>(ep.bias + n);
+            v += pre_bias;
             float* p = reinterpret_cast<float*>(ep.out) + (size_t)m * ep.ldo + n;
-            v = *reinterpret_cast<const f32x4*>(p) + v;
+            v = ((t == wave) ? pre_res : *reinterpret_cast<const f32x4*>(p)) + v;
             *reinterpret_cast<f32x4*>(p) = v;
             if (ep.xb_out) {  // bf16 copy of the new residual rows: the A operand of the next folded GEMM
                 u32x2 pk;
@@ -219,11 +235,12 @@ static int launch_gemm_skinny_mt(hipStream_t st, const void* A, const void* W, c
         double best = 1e30;
         for (int mt = 1; mt <= 16; mt *= 2) {
             const double wgs = (double)(N / 16) * ((tiles + mt - 1) / mt);
-            // long K: a workgroup lasts long enough that a partly filled round costs a whole one (FC2 at 100 rows:
-            // 2 x 192 workgroups 10.1 us vs 336 workgroups 12.7 us); short K: the dispatcher smooths partial rounds
-            double rounds = wgs > 256.0 ? wgs / 256.0 : 1.0;
-            if (K >= 2048) rounds = (double)(int64_t)((wgs + 255.0) / 256.0);
-            const double cost = (1.0 + mt) * rounds;
+            // A workgroup is latency, not bandwidth: ~2.4 us of fixed cost + ~0.67 us per 16-row operand tile it moves
+            // (out-proj at 50 rows: MT = 1 3.7 us, MT = 4 5.7 us), and a partly filled round costs a whole one at every K —
+            // round 3, rocprofv3 of one request: QKV as 288 workgroups (MT = 2) 8.9 us = two rounds of 4.4; as 144
+            // workgroups (MT = 4) one round. (Round 2 counted fractional rounds for short K.)
+            const double rounds = (double)(int64_t)((wgs + 255.0) / 256.0);
+            const double cost = (K >= 2048 ? (1.0 + mt) : (3.6 + 1.0 + mt)) * rounds;
             if (cost < best - 1e-9) { best = cost; per = mt; }
             if (mt >= tiles) break;
         }
