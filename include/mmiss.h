@@ -205,6 +205,9 @@ int mmiss_index_labels(mmiss_index* idx, int64_t* out, int64_t cap);
  * out_labels int64 [Q,k], out_dist float32 [Q,k] = cosine distance 1 - cos, ascending; ties by label
  * ascending. out_count int32 [Q] = min(k, count); unused slots hold label -1 / distance +inf.
  * k larger than count is not an error (the UI's "All" sends 1000 — backend/app/main.py:757).
+ * Synchronisation: the exactness guard (below) reads ONE flag word back per call to decide on the host whether any query
+ * must be widened, so the call waits for its own work on the stream it runs on — also on a caller's stream with device
+ * outputs (mmiss_index_set_stream(.., use_own = 0)), and it cannot be captured into a HIP graph (the encode calls can).
  * replaces collection.query(query_embeddings, n_results, include=["metadatas","distances"]) —
  *          backend/app/main.py:761-765
  */

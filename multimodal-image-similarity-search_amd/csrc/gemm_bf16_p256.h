@@ -116,24 +116,37 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 4, vo, so, 0, 0)
 // LIVE = false: the slot is not read (the A m1 slot of a half tile): its two pieces shrink to 4 bytes per lane — the K
 // stream is bound by LDS-DMA bytes per CU (64 KB per K-tile at ~40 GB/s), the operation COUNT must stay what the waits assume
-#define P256_STAGE(which, b, oA, oW, LIVE)                                                                   \
+// PCS: which of the slot's two 8-row pieces (bit 0 / bit 1)
+#define P256_STAGE_P(which, b, oA, oW, LIVE, PCS)                                                            \
     if constexpr (!((DBG & 2) != 0)) {                                                                      \
         char* dst_ = smem + P256_SLOT(which, b) + stage_dst;                                                \
         if constexpr ((which) < 2) {                                                                        \
             const int so_ = (oA);                                                                           \
             if (LIVE) {                                                                                     \
-                P256_BLDS(srdA, a_vo, so_, dst_);                                                           \
-                P256_BLDS(srdA, a_vo, so_ + row8, dst_ + 1024);                                             \
+                if constexpr (((PCS) & 1) != 0) P256_BLDS(srdA, a_vo, so_, dst_);                           \
+                if constexpr (((PCS) & 2) != 0) P256_BLDS(srdA, a_vo, so_ + row8, dst_ + 1024);             \
             } else {                                                                                        \
-                P256_BLDS4(srdA, a_vo, so_, dst_);                                                          \
-                P256_BLDS4(srdA, a_vo, so_ + row8, dst_ + 1024);                                            \
+                if constexpr (((PCS) & 1) != 0) P256_BLDS4(srdA, a_vo, so_, dst_);                          \
+                if constexpr (((PCS) & 2) != 0) P256_BLDS4(srdA, a_vo, so_ + row8, dst_ + 1024);            \
             }                                                                                               \
         } else {                                                                                            \
             const int so_ = (oW) + ((which) & 1) * 4 * row8;                                                \
-            P256_BLDS(srdW, w_vo, so_, dst_);                                                               \
-            P256_BLDS(srdW, w_vo, so_ + row8, dst_ + 1024);                                                 \
+            if constexpr (((PCS) & 1) != 0) P256_BLDS(srdW, w_vo, so_, dst_);                               \
+            if constexpr (((PCS) & 2) != 0) P256_BLDS(srdW, w_vo, so_ + row8, dst_ + 1024);                 \
         }                                                                                                   \
     }
+// Both pieces of a slot are issued in the read part of the phase. P256_SPLIT_STAGE issues the second one from the middle of
+// the MFMA part instead (where a piece is said to cost ~60 cycles of issue against 100-185 beside fragment reads): measured
+// 3-6 % SLOWER (4096^3: 116-121 vs 111-113 us on one box, tools/p256_split_ab.sh) — the read part is not what bounds the loop.
+#ifndef P256_SPLIT_STAGE
+#define P256_STAGE(which, b, oA, oW, LIVE) P256_STAGE_P(which, b, oA, oW, LIVE, 3)
+#define P256_STAGE_MID(which, b, oA, oW, LIVE)
+#define P256_INFLIGHT 10
+#else
+#define P256_STAGE(which, b, oA, oW, LIVE) P256_STAGE_P(which, b, oA, oW, LIVE, 1)
+#define P256_STAGE_MID(which, b, oA, oW, LIVE) P256_STAGE_P(which, b, oA, oW, LIVE, 2)
+#define P256_INFLIGHT 9
+#endif
     // what the epilogue of tile (bm, bn) reads from memory, by LDS-DMA: 1 + XP pieces per wave
     auto stage_x = [&](int bm, int bn, int par) {
         const float* src = ((FOLD && wave >= 4) ? ep.aux : ep.bias) + bn * 256 + (wave & 3) * 64 + lane;
@@ -175,24 +188,31 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
             wq[nq][nf][1] = *reinterpret_cast<const frag*>(smem + wb[1] + P256_SLOT(nq, b) + nf * 2048);    \
         }                                                                                                   \
     }
-#define P256_MMA(mq, nq)                                                                                     \
+#define P256_MMA_HALF(mq, nq, s)                                                                             \
+    _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                        \
+        _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                                    \
+            acc[(nq) * 2 + nf][(mq) * 4 + mf] = MfmaIn<IN_T>::mma(                                          \
+                wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf]);
+// 16 MFMAs with MID (a slot's second LDS-DMA piece, or nothing) issued behind the first eight
+#define P256_MMA(mq, nq, MID)                                                                                \
     if constexpr ((DBG & 1) != 0) {                                                                         \
         _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) asm volatile("" ::"v"(am[mf][0]), "v"(am[mf][1]));  \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) asm volatile("" ::"v"(wq[nq][nf][0]), "v"(wq[nq][nf][1])); \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                    \
             _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) asm volatile("" : "+v"(acc[(nq) * 2 + nf][(mq) * 4 + mf])); \
+        MID;                                                                                                \
     } else {                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                                      \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
-            _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                \
-                _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                            \
-                    acc[(nq) * 2 + nf][(mq) * 4 + mf] = MfmaIn<IN_T>::mma(                                  \
-                        wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf]);                       \
+        P256_MMA_HALF(mq, nq, 0)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        MID;                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        P256_MMA_HALF(mq, nq, 1)                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     }
-// counted wait: 10 = the five slot loads (2 pieces each) that stay in flight; POST = the stores and pieces of the
+// counted wait: P256_INFLIGHT = the pieces of the younger slot loads that stay in flight (four slots and a half: 9); POST = the stores and pieces of the
 // previous tile's epilogue are younger than the slot waited for
-#define P256_WAIT(POST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((POST) ? 10 + EX : 10) : "memory")
+#define P256_WAIT(POST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((POST) ? P256_INFLIGHT + EX : P256_INFLIGHT) : "memory")
 #define P256_BARRIER()                                                \
     {                                                                 \
         __builtin_amdgcn_sched_barrier(0);                            \
@@ -219,26 +239,28 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         P256_LATE_READS_DONE();                                                                             \
         P256_WAIT(P0);                    /* retires W n1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
-        P256_MMA(0, 0);                                                                                     \
+        P256_MMA(0, 0, P256_STAGE_MID(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0));                               \
         P256_BARRIER();                                                                                     \
         P256_READ_W(B, 1);                                                                                  \
         P256_STAGE(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                          \
         P256_LATE_READS_DONE();                                                                             \
         P256_WAIT(P1);                    /* retires A m1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
-        P256_MMA(0, 1);                                                                                     \
+        P256_MMA(0, 1, P256_STAGE_MID(0, B, oA2, oW2, true));                                               \
         P256_BARRIER();                                                                                     \
         if constexpr (!(HALF)) P256_READ_A(B, 1);                                                           \
         P256_STAGE(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
         P256_LATE_READS_DONE();                                                                             \
         P256_BARRIER();                                                                                     \
-        if constexpr (!(HALF)) P256_MMA(1, 1);                                                              \
+        if constexpr (!(HALF)) { P256_MMA(1, 1, P256_STAGE_MID(2, B, oA2, oW2, true)); }                    \
+        else { P256_STAGE_MID(2, B, oA2, oW2, true); }                                                      \
         P256_BARRIER();                                                                                     \
         P256_STAGE(3, B, oA2, oW2, true);       /* W n1 of K-tile t+2 */                                          \
         P256_FIN_HOOK(FIN);                                                                                 \
         P256_WAIT(P3);                    /* retires A m0 / W n0 of the next K-tile */                      \
         P256_BARRIER();                                                                                     \
-        if constexpr (!(HALF)) P256_MMA(1, 0);                                                              \
+        if constexpr (!(HALF)) { P256_MMA(1, 0, P256_STAGE_MID(3, B, oA2, oW2, true)); }                    \
+        else { P256_STAGE_MID(3, B, oA2, oW2, true); }                                                      \
         P256_BARRIER();                                                                                     \
         P256_ADVANCE();                                                                                     \
     }
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     oA1 = oA2; oW1 = oW2;
     oA2 += GEMM_BK * 2; oW2 += GEMM_BK * 2;
     k2 = 2;
-    P256_WAIT(false);  // all but the five youngest slot loads: A m0 / W n0 of K-tile 0 (and the epilogue pieces) have landed
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // all but the five youngest slot loads: A m0 / W n0 of K-tile 0 (and the epilogue pieces) have landed
     P256_BARRIER();
     if (wm == 1) P256_BARRIER();  // the lower half runs one barrier behind from here on
 
@@ -556,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     oA1 = oA2; oW1 = oW2;
     oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * (int)sizeof(IN);
     k2 = 2;
-    P256_WAIT(false);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     P256_BARRIER();
     if (wm == 1) P256_BARRIER();
 
@@ -612,6 +634,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
 }
 
 #undef P256_STAGE
+#undef P256_STAGE_P
+#undef P256_STAGE_MID
+#undef P256_INFLIGHT
+#undef P256_MMA_HALF
 #undef P256_SLOT
 #undef P256_BLDS
 #undef P256_BLDS4

@@ -1,0 +1,10 @@
+set -u
+cd "$GRAFT_REPO_ROOT"
+run() { for i in 1 2; do python tools/gemm_p256_probe.py; EPI=7 N=2304 python tools/gemm_p256_probe.py; M=4096 N=4096 K=4096 EPI=1 ITERS=20 python tools/gemm_p256_probe.py; done 2>&1 | grep -v amdgpu; }
+echo "== both pieces in the read part (default)"
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "p256" 2>&1 | tail -1
+run
+echo "== split staging (second piece of a slot issued from the middle of the MFMA part)"
+make -C multimodal-image-similarity-search_amd/csrc clean > /dev/null
+make -C multimodal-image-similarity-search_amd/csrc -j16 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -DP256_SPLIT_STAGE" > gpurun_out/ab_build.log 2>&1 || tail -5 gpurun_out/ab_build.log
+run
