@@ -670,7 +670,7 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         // It costs four extra small launches (~35 us), so it is taken when the matrix it avoids is worth more: from
         // Q x N = 10^9 scores (256 MB of group maxima written and read back). Option score_filter: 0 never, 2 whenever possible.
         const int64_t nbn = Npad / 256;
-        const int64_t ns_tiles = std::max<int64_t>(16, nbn / 32);
+        const int64_t ns_tiles = std::max<int64_t>(16, nbn / mmiss_option("score_sample_div", 32));
         const int filter_opt = mmiss_option("score_filter", 1);
         const bool filtered = big && nbn >= 128 && filter_opt != 0 && (filter_opt == 2 || (double)Mq * (double)Npad >= 1e9);
         const int64_t Ndense = filtered ? ns_tiles * 256 : Npad;   // rows whose group maxima are materialised
@@ -686,6 +686,22 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
             // >= 8 workgroups per CU for balance
             const int64_t tiles = nbn * (Mq / 256);
             strip = (int)std::min<int64_t>(32, std::max<int64_t>(1, tiles / 2048));
+            // Round 3: the workgroups of a launch run in rounds of one per CU, and a last round of a few workgroups costs a
+            // whole strip (10M rows x 1024 queries: strip 32 gave 4884 workgroups = 19.08 rounds of 256 -> 5 % of the launch
+            // spent with 18 workgroups on the chip). Among the strip lengths down to half the rule's, take the one whose
+            // rounds x length (+ a quarter tile of pipeline fill per workgroup and round) is smallest.
+            if (strip >= 8 && mmiss_option("score_strip_fit", 1) != 0) {
+                const int64_t ncol = filtered ? nbn - ns_tiles : nbn;   // column tiles of the LONG launch
+                double best = 1e300;
+                int best_s = strip;
+                for (int sl = strip; sl >= strip / 2; --sl) {
+                    const int64_t wgs = (Mq / 256) * ((ncol + sl - 1) / sl);
+                    const int64_t rounds = (wgs + 255) / 256;
+                    const double cost = (double)rounds * (sl + 0.25);
+                    if (cost < best - 1e-9) { best = cost; best_s = sl; }
+                }
+                strip = best_s;
+            }
             const int forced = mmiss_option("score_strip", 0);
             if (forced > 0) strip = forced;
         }
