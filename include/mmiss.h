@@ -205,14 +205,27 @@ int mmiss_index_labels(mmiss_index* idx, int64_t* out, int64_t cap);
  * out_labels int64 [Q,k], out_dist float32 [Q,k] = cosine distance 1 - cos, ascending; ties by label
  * ascending. out_count int32 [Q] = min(k, count); unused slots hold label -1 / distance +inf.
  * k larger than count is not an error (the UI's "All" sends 1000 — backend/app/main.py:757).
- * Synchronisation: the exactness guard (below) reads ONE flag word back per call to decide on the host whether any query
- * must be widened, so the call waits for its own work on the stream it runs on — also on a caller's stream with device
- * outputs (mmiss_index_set_stream(.., use_own = 0)), and it cannot be captured into a HIP graph (the encode calls can).
+ * Synchronisation: the exactness guard (below) decides on the host whether any query must be widened (the last kernel
+ * leaves one flag per query in a pinned host block; no copy-engine operation), so the call waits for its own work on the
+ * stream it runs on — also on a caller's stream with device outputs (mmiss_index_set_stream(.., use_own = 0)), and it
+ * cannot be captured into a HIP graph (the encode calls can). mmiss_index_query_begin / _end split that wait off.
  * replaces collection.query(query_embeddings, n_results, include=["metadatas","distances"]) —
  *          backend/app/main.py:761-765
  */
 int mmiss_index_query(mmiss_index* idx, const float* queries, int32_t Q, int32_t k,
                       int64_t* out_labels, float* out_dist, int32_t* out_count);
+/*
+ * The same query in two halves, for a caller that keeps the GPU fed while it waits (a serving loop: queue the NEXT batch's
+ * encode between the two calls, bench.py does). _begin queues the first pass on the index's stream and returns without
+ * waiting; _end waits for exactly that work (an event, not the stream: whatever the caller queued behind it keeps running),
+ * runs the guard's widen pass for the queries that need it, and fills host outputs. mmiss_index_query = _begin + _end.
+ * Between the two calls `queries` and the output buffers must stay valid, and every other call on this index except
+ * count / labels / guard_stats fails with MMISS_ERR_STATE (the scratch buffers belong to the open query); _end without
+ * _begin -> MMISS_ERR_STATE. No reference analogue: collection.query is synchronous (backend/app/main.py:761-765).
+ */
+int mmiss_index_query_begin(mmiss_index* idx, const float* queries, int32_t Q, int32_t k,
+                            int64_t* out_labels, float* out_dist, int32_t* out_count);
+int mmiss_index_query_end(mmiss_index* idx);
 /*
  * Exactness accounting since the index was created ("top-10 recall = 1.0" is proven per query, not assumed): the first
  * pass ranks by approximate matrix-core scores and keeps k' > k rows; a query whose k-th exact score does not clear the

@@ -81,6 +81,8 @@ SIGNATURES = {
     "mmiss_index_get": (_I, [_P, _P, _I64, _P]),
     "mmiss_index_labels": (_I, [_P, _P, _I64]),
     "mmiss_index_query": (_I, [_P, _P, _I32, _I32, _P, _P, _P]),
+    "mmiss_index_query_begin": (_I, [_P, _P, _I32, _I32, _P, _P, _P]),
+    "mmiss_index_query_end": (_I, [_P]),
     "mmiss_index_guard_stats": (_I, [_P, C.POINTER(_I64)]),
     "mmiss_index_guard_stats_ex": (_I, [_P, C.POINTER(_I64)]),
     "mmiss_index_save": (_I, [_P, C.c_char_p]),

@@ -20,15 +20,40 @@ struct mmiss_index {
     DevBuf rows, labels_d;
     std::vector<int64_t> labels_h;
     // scratch
-    DevBuf stage, qn, qs, qstage, lists_s, lists_r, lists2_s, lists2_r, cand, cur_s, cur_r, out_l, out_d, out_c, map, gmax;
+    DevBuf stage, qn, qs, qstage, lists_s, lists_r, lists2_s, lists2_r, cand, cur_s, cur_r, out_c, map, gmax;
     // exactness guard + widen pass (see "exactness contract" above mmiss_index_query)
     DevBuf flags, nflag_d, qmap, qmap64, qs2, cand2, cur2_s, cur2_r;
     DevBuf seed_s, seed_r, fcnt, fbuf_s, fbuf_g;  // threshold-filtered selection (Q > 128)
     int32_t* nflag_h = nullptr;  // pinned
+    // Pinned, device-visible host block a query's LAST kernel (the rerank) writes straight into: the guard's per-query flags
+    // always, and labels / distances / counts when the caller's outputs are host buffers. The call then ends with ONE stream
+    // synchronisation and no copy-engine operation (round 3: four small device-to-host copies used to sit there, ~25 us).
+    char* pin = nullptr;
+    size_t pin_bytes = 0;
+    int ensure_pin(size_t need) {
+        if (need <= pin_bytes) return MMISS_OK;
+        size_t cap = pin_bytes ? pin_bytes : 4096;
+        while (cap < need) cap *= 2;
+        if (pin) { MM_HIP(hipStreamSynchronize(stream())); MM_HIP(hipHostFree(pin)); pin = nullptr; pin_bytes = 0; }
+        MM_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin), cap, hipHostMallocDefault));
+        pin_bytes = cap;
+        return MMISS_OK;
+    }
     int64_t stat_queries = 0, stat_flagged = 0, stat_rounds = 0, stat_pages = 0, stat_exhaustive = 0;
+    // a query between mmiss_index_query_begin and mmiss_index_query_end: its first pass is queued, `done_ev` marks its end
+    struct Pending {
+        bool active = false, out_dev = false, guard = false;
+        int Q = 0, k = 0;
+        int64_t* d_lab = nullptr; float* d_dist = nullptr; int32_t* d_cnt = nullptr; int32_t* h_flags = nullptr;
+        int64_t* out_labels = nullptr; float* out_dist = nullptr; int32_t* out_count = nullptr;
+    } pend;
     DevBuf dist_all;  // exhaustive fallback: one canonical distance per row
     hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
 };
+
+// every other entry point refuses to run between query_begin and query_end (the scratch buffers belong to that query)
+#define MM_NO_PENDING(ix, who) \
+    do { if ((ix)->pend.active) MM_FAIL(MMISS_ERR_STATE, "%s: a query begun with mmiss_index_query_begin is still open", who); } while (0)
 
 namespace {
 
@@ -201,6 +226,7 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
     (void)hipDeviceSynchronize();
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     if (ix->nflag_h) (void)hipHostFree(ix->nflag_h);
+    if (ix->pin) (void)hipHostFree(ix->pin);
     if (ix->done_ev) (void)hipEventDestroy(ix->done_ev);
     delete ix;
     return MMISS_OK;
@@ -209,6 +235,7 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
 extern "C" int mmiss_index_set_stream(mmiss_index* ix, void* hip_stream, int32_t use_own) {
     if (!ix) MM_FAIL(MMISS_ERR_ARG, "null index");
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_set_stream");
     hipStream_t next = reinterpret_cast<hipStream_t>(hip_stream);
     const bool next_user = use_own == 0;
     if (next_user != ix->has_user_stream || (next_user && next != ix->user_stream)) {
@@ -233,6 +260,7 @@ extern "C" int mmiss_index_count(mmiss_index* ix, int64_t* count) {
 extern "C" int mmiss_index_clear(mmiss_index* ix) {
     if (!ix) MM_FAIL(MMISS_ERR_ARG, "null index");
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_clear");
     ix->count = 0;
     ix->labels_h.clear();
     return MMISS_OK;
@@ -244,6 +272,7 @@ extern "C" int mmiss_index_add(mmiss_index* ix, const float* vecs, const int64_t
     if (n < 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_add: n = %lld", (long long)n);
     if (n == 0) return MMISS_OK;
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_add");
     MM_TRY(mmiss_use_device(ix->device));
     hipStream_t st = ix->stream();
     std::vector<int64_t> lab;
@@ -283,6 +312,7 @@ extern "C" int mmiss_index_update(mmiss_index* ix, const int64_t* labels, const 
     if (!ix || (n > 0 && (!vecs || !labels))) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_update: null argument");
     if (n <= 0) return n == 0 ? MMISS_OK : MMISS_ERR_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_update");
     MM_TRY(mmiss_use_device(ix->device));
     hipStream_t st = ix->stream();
     std::vector<int64_t> lab;
@@ -310,6 +340,7 @@ extern "C" int mmiss_index_remove(mmiss_index* ix, const int64_t* labels, int64_
     if (removed) *removed = 0;
     if (n <= 0) return n == 0 ? MMISS_OK : MMISS_ERR_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_remove");
     MM_TRY(mmiss_use_device(ix->device));
     hipStream_t st = ix->stream();
     std::vector<int64_t> lab;
@@ -355,6 +386,7 @@ extern "C" int mmiss_index_get(mmiss_index* ix, const int64_t* labels, int64_t n
     if (!ix || (n > 0 && (!labels || !out))) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_get: null argument");
     if (n <= 0) return n == 0 ? MMISS_OK : MMISS_ERR_ARG;
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_get");
     MM_TRY(mmiss_use_device(ix->device));
     hipStream_t st = ix->stream();
     std::vector<int64_t> lab;
@@ -579,12 +611,11 @@ int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
 }  // namespace
 
 // ================================================================================================ query
-extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t Q, int32_t k, int64_t* out_labels,
-                                 float* out_dist, int32_t* out_count) {
-    if (!ix || !queries || !out_labels || !out_dist) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query: null argument");
-    if (Q < 0 || k <= 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query: Q=%d k=%d", Q, k);
-    if (Q == 0) return MMISS_OK;
-    std::lock_guard<std::mutex> lk(ix->mu);
+namespace {
+
+// first pass of a query: everything up to and including the rerank is QUEUED on the stream; ix->pend describes it
+int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t k, int64_t* out_labels, float* out_dist,
+                       int32_t* out_count) {
     MM_TRY(mmiss_use_device(ix->device));
     hipStream_t st = ix->stream();
     const int D = ix->dim;
@@ -593,15 +624,18 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     if (out_dev != mmiss_is_device_ptr(out_dist) || (out_count && out_dev != mmiss_is_device_ptr(out_count)))
         MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query: output pointers must be all host or all device");
 
-    // outputs on device
+    // outputs: the caller's device buffers, or the pinned host block (copied to the caller's host buffers at the end)
     int64_t* d_lab = out_labels; float* d_dist = out_dist; int32_t* d_cnt = out_count;
+    const size_t pin_lab = 0, pin_dist = (size_t)Q * k * 8, pin_cnt = pin_dist + (size_t)Q * k * 4, pin_flags = pin_cnt + (size_t)Q * 4;
+    MM_TRY(ix->ensure_pin(pin_flags + (size_t)Q * 4));
     if (!out_dev) {
-        MM_TRY(ix->out_l.ensure((size_t)Q * k * 8));
-        MM_TRY(ix->out_d.ensure((size_t)Q * k * 4));
-        d_lab = ix->out_l.as<int64_t>(); d_dist = ix->out_d.as<float>();
+        d_lab = reinterpret_cast<int64_t*>(ix->pin + pin_lab); d_dist = reinterpret_cast<float*>(ix->pin + pin_dist);
+        d_cnt = reinterpret_cast<int32_t*>(ix->pin + pin_cnt);
+    } else if (!out_count) {
+        MM_TRY(ix->out_c.ensure((size_t)Q * 4));
+        d_cnt = ix->out_c.as<int32_t>();
     }
-    MM_TRY(ix->out_c.ensure((size_t)Q * 4));
-    if (!out_dev || !out_count) d_cnt = ix->out_c.as<int32_t>();
+    int32_t* const h_flags = reinterpret_cast<int32_t*>(ix->pin + pin_flags);
 
     // effective k: never more than the rows there are
     int kp, pages;
@@ -645,10 +679,9 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
     MM_TRY(ix->cur_s.ensure((size_t)Q * 4));
     MM_TRY(ix->cur_r.ensure((size_t)Q * 4));
     const bool guard = N > 0 && mmiss_option("exact_guard", 1) != 0;
-    if (guard) {
+    if (guard) {  // the widen pass keeps its own (device) flags and counter
         MM_TRY(ix->flags.ensure((size_t)Q * 4));
         MM_TRY(ix->nflag_d.ensure(64));
-        MM_HIP(hipMemsetAsync(ix->nflag_d.p, 0, 4, st));
     }
     const int32_t* ovf_cnt = nullptr;  // threshold-filtered selection: per-query append counts and their capacity
     int ovf_cap = 0;
@@ -802,48 +835,83 @@ extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t 
         r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
         if (guard) {
             r.tau = ix->cur_s.as<float>(); r.eps = guard_eps(ix);
-            r.flags = ix->flags.as<int32_t>(); r.nflag = ix->nflag_d.as<int32_t>();
+            r.flags = h_flags; r.nflag = nullptr;  // one plain store per query into the pinned block; counted on the host
             r.force_flag = mmiss_option("guard_force", 0);
             r.ovf_cnt = ovf_cnt; r.ovf_cap = ovf_cap;
         }
         MM_TRY(launch_rerank(ix, st, r, Q));
     }
     ix->stat_queries += Q;
-    auto copy_out = [&]() -> int {  // results to the caller's host buffers
-        MM_HIP(hipMemcpyAsync(out_labels, d_lab, (size_t)Q * k * 8, hipMemcpyDeviceToHost, st));
-        MM_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)Q * k * 4, hipMemcpyDeviceToHost, st));
-        if (out_count) MM_HIP(hipMemcpyAsync(out_count, d_cnt, (size_t)Q * 4, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipEventRecord(ix->done_ev, st));
+    mmiss_index::Pending& pd = ix->pend;
+    pd.active = true; pd.out_dev = out_dev; pd.guard = guard; pd.Q = Q; pd.k = k;
+    pd.d_lab = d_lab; pd.d_dist = d_dist; pd.d_cnt = d_cnt; pd.h_flags = h_flags;
+    pd.out_labels = out_labels; pd.out_dist = out_dist; pd.out_count = out_count;
+    return MMISS_OK;
+}
+
+// second half: wait for the first pass (its event, NOT the stream: the caller may have queued the next batch's encode behind
+// it), widen what the guard could not prove, hand host outputs over
+int query_end_locked(mmiss_index* ix) {
+    mmiss_index::Pending pd = ix->pend;
+    ix->pend.active = false;
+    MM_TRY(mmiss_use_device(ix->device));
+    hipStream_t st = ix->stream();
+    if (!pd.guard && pd.out_dev && ix->has_user_stream) {  // device outputs on the caller's stream, nothing to decide: stays queued
+        ix->async_pending = true;
         return MMISS_OK;
-    };
-    bool copied = false;
-    if (guard) {
-        // one 4-byte read-back per call: how many queries could not be proven exact (almost always 0). With host outputs the
-        // results ride in front of it, so the call still has ONE stream synchronisation.
-        if (!out_dev) { MM_TRY(copy_out()); copied = true; }
-        int nflag = 0;
-        MM_TRY(read_nflag(ix, st, &nflag));
-        if (nflag > 0) {
-            std::vector<int32_t> fl((size_t)Q), which;
-            MM_HIP(hipMemcpy(fl.data(), ix->flags.p, (size_t)Q * 4, hipMemcpyDeviceToHost));
-            for (int q = 0; q < Q; ++q)
-                if (fl[q]) which.push_back(q);
+    }
+    MM_HIP(hipEventSynchronize(ix->done_ev));
+    if (pd.guard) {
+        std::vector<int32_t> which;
+        for (int q = 0; q < pd.Q; ++q)
+            if (pd.h_flags[q]) which.push_back(q);
+        if (!which.empty()) {
             ix->stat_flagged += (int64_t)which.size();
-            MM_TRY(widen_queries(ix, st, which, k, d_lab, d_dist, d_cnt));
-            copied = false;  // the widened rows replace what was copied
+            MM_TRY(widen_queries(ix, st, which, pd.k, pd.d_lab, pd.d_dist, pd.d_cnt));  // returns with the stream drained
         }
     }
-    if (!out_dev) {
-        if (!copied) {
-            MM_TRY(copy_out());
-            MM_HIP(hipStreamSynchronize(st));
-        }
-    } else if (!ix->has_user_stream) {
-        if (!guard) MM_HIP(hipStreamSynchronize(st));
-    } else {
-        MM_HIP(hipEventRecord(ix->done_ev, st));
-        ix->async_pending = true;
+    if (!pd.out_dev) {
+        memcpy(pd.out_labels, pd.d_lab, (size_t)pd.Q * pd.k * 8);
+        memcpy(pd.out_dist, pd.d_dist, (size_t)pd.Q * pd.k * 4);
+        if (pd.out_count) memcpy(pd.out_count, pd.d_cnt, (size_t)pd.Q * 4);
     }
     return MMISS_OK;
+}
+
+int query_check_args(const mmiss_index* ix, const float* queries, int32_t Q, int32_t k, const int64_t* out_labels,
+                     const float* out_dist, const char* who) {
+    if (!ix || !queries || !out_labels || !out_dist) MM_FAIL(MMISS_ERR_ARG, "%s: null argument", who);
+    if (Q < 0 || k <= 0) MM_FAIL(MMISS_ERR_ARG, "%s: Q=%d k=%d", who, Q, k);
+    return MMISS_OK;
+}
+
+}  // namespace
+
+extern "C" int mmiss_index_query(mmiss_index* ix, const float* queries, int32_t Q, int32_t k, int64_t* out_labels,
+                                 float* out_dist, int32_t* out_count) {
+    MM_TRY(query_check_args(ix, queries, Q, k, out_labels, out_dist, "mmiss_index_query"));
+    if (Q == 0) return MMISS_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_query");
+    MM_TRY(query_begin_locked(ix, queries, Q, k, out_labels, out_dist, out_count));
+    return query_end_locked(ix);
+}
+
+extern "C" int mmiss_index_query_begin(mmiss_index* ix, const float* queries, int32_t Q, int32_t k, int64_t* out_labels,
+                                       float* out_dist, int32_t* out_count) {
+    MM_TRY(query_check_args(ix, queries, Q, k, out_labels, out_dist, "mmiss_index_query_begin"));
+    if (Q == 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query_begin: Q = 0");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_query_begin");
+    return query_begin_locked(ix, queries, Q, k, out_labels, out_dist, out_count);
+}
+
+extern "C" int mmiss_index_query_end(mmiss_index* ix) {
+    if (!ix) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query_end: null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->pend.active) MM_FAIL(MMISS_ERR_STATE, "mmiss_index_query_end: no query was begun");
+    return query_end_locked(ix);
 }
 
 extern "C" int mmiss_index_guard_stats_ex(mmiss_index* ix, int64_t out[8]) {
@@ -874,6 +942,7 @@ struct IdxHeader {
 extern "C" int mmiss_index_save(mmiss_index* ix, const char* path) {
     if (!ix || !path) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_save: null argument");
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_save");
     MM_TRY(mmiss_use_device(ix->device));
     MM_HIP(hipStreamSynchronize(ix->stream()));
     FILE* f = fopen(path, "wb");
@@ -900,6 +969,7 @@ extern "C" int mmiss_index_save(mmiss_index* ix, const char* path) {
 extern "C" int mmiss_index_load(mmiss_index* ix, const char* path) {
     if (!ix || !path) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_load: null argument");
     std::lock_guard<std::mutex> lk(ix->mu);
+    MM_NO_PENDING(ix, "mmiss_index_load");
     MM_TRY(mmiss_use_device(ix->device));
     hipStream_t st = ix->stream();
     FILE* f = fopen(path, "rb");

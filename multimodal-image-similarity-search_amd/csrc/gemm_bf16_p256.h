@@ -89,7 +89,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     // (decoded ONCE, in parallel, into LDS: the integer divisions are VALU code on this target, and inlined at the places of
     // the unrolled K loop that move on to a next tile they pushed the kernel over its 256 registers: 233 spilled, 6 x slower)
     auto tile_of = [&](int i, int& bm, int& bn, int& half) {  // half: 0 whole tile, 1 / 2 = its m0 / m1 rows only
-        const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane(reinterpret_cast<const volatile int*>(smem + P256_TILES)[i]);
+        // (an LDS-address-space load: through a generic pointer this was a flat_load + s_waitcnt vmcnt(0) — a drain of the
+        // whole staging pipeline at every tile switch)
+        const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane(((const __attribute__((address_space(3))) int*)(smem + P256_TILES))[i]);
         bm = pk & 0xffff;
         bn = (pk >> 16) & 0x3fff;
         half = (pk >> 30) ? 1 + (int)(pk >> 31) : 0;

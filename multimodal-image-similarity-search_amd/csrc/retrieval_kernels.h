@@ -177,6 +177,16 @@ struct ScanLds {
     static __host__ __device__ int round_up16(int x) { return (x + 15) & ~15; }
 };
 
+// A stored row is read ONCE per query block by one wave: a stream. MMISS_SCAN_NT marks the loads non-temporal so that a
+// scan does not push the towers' weights out of the 256 MB Infinity Cache between two requests (tools/scan_nt_ab.sh).
+__device__ __forceinline__ u32x4 scan_row_load(const u32x4* p) {
+#ifdef MMISS_SCAN_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 template <typename T, int NQT, int CAP, int GS = 8>
 __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
             constexpr int NS = decltype(nsteps_tag)::value;
             u32x4 araw[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) araw[s] = *reinterpret_cast<const u32x4*>(rp + byte0 + s * 64);
+            for (int s = 0; s < NS; ++s) araw[s] = scan_row_load(reinterpret_cast<const u32x4*>(rp + byte0 + s * 64));
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -608,7 +618,7 @@ struct RerankArgs {
     int32_t* out_rows;      // [blocks][cand_stride], first k_eff entries written, or null
     // exactness guard (see api_index.hip "exactness contract"): tau[b] = stage 1's bound on the approximate score of every
     // row that is NOT among the candidates (-inf: every row is a candidate). The result is proven exact when the k-th
-    // canonical score clears tau by more than eps; otherwise flags[b] = 1 and *nflag counts it.
+    // canonical score clears tau by more than eps; otherwise flags[b] = 1 and *nflag (when given) counts it.
     const float* tau;
     double eps;
     int32_t* flags;
@@ -736,7 +746,7 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
                 }
             }
             a.flags[b] = flag;
-            if (flag) atomicAdd(a.nflag, 1);
+            if (flag && a.nflag) atomicAdd(a.nflag, 1);
         }
     }
 }

@@ -104,6 +104,15 @@ class FlatIndex:
     def query(self, queries, k: int) -> Tuple["np.ndarray", "np.ndarray", "np.ndarray"]:
         """-> (labels int64 [Q,k], distances float32 [Q,k], counts int32 [Q]); numpy in -> numpy out,
         CUDA tensor in -> CUDA tensors out (no host round trip)."""
+        return self._query(queries, k, split=False)
+
+    def query_begin(self, queries, k: int) -> "PendingQuery":
+        """Queue the query's first pass and return at once (mmiss_index_query_begin); `.result()` of the returned handle waits
+        for it, widens what the exactness guard could not prove, and returns what query() returns. Between the two the caller
+        may queue other GPU work on the same stream (the next batch's encode) — but no other call on this index."""
+        return self._query(queries, k, split=True)
+
+    def _query(self, queries, k: int, split: bool):
         q = self._vecs(queries)
         Q = int(q.shape[0])
         if _is_torch(q) and q.is_cuda:
@@ -120,8 +129,9 @@ class FlatIndex:
             cnt = np.empty((Q,), dtype=np.int32)
         with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
             self._sync_stream(q)
-            _lib.check(self._lib.mmiss_index_query(self._h, _lib.ptr(q), Q, int(k), _lib.ptr(lab), _lib.ptr(dist), _lib.ptr(cnt)))
-        return lab, dist, cnt
+            fn = self._lib.mmiss_index_query_begin if split else self._lib.mmiss_index_query
+            _lib.check(fn(self._h, _lib.ptr(q), Q, int(k), _lib.ptr(lab), _lib.ptr(dist), _lib.ptr(cnt)))
+        return PendingQuery(self, q, (lab, dist, cnt)) if split else (lab, dist, cnt)
 
     def guard_stats(self) -> dict:
         """Exactness accounting (mmiss_index_guard_stats): queries served, queries whose first pass could not be proven
@@ -148,6 +158,21 @@ class FlatIndex:
             self.close()
         except Exception:
             pass
+
+
+class PendingQuery:
+    """A query between FlatIndex.query_begin and its result(): holds the query rows and the output buffers alive."""
+
+    def __init__(self, index: "FlatIndex", q, outs):
+        self._index, self._q, self._outs, self._done = index, q, outs, False
+
+    def result(self):
+        if not self._done:
+            with self._index._call_lock:
+                _lib.check(self._index._lib.mmiss_index_query_end(self._index._h))
+            self._done = True
+            self._q = None
+        return self._outs
 
 
 def blend(img, txt, weight_image: float, device: int = 0):

@@ -380,3 +380,50 @@ def test_merge_topk_any_shard_count(mods, S, k, Q):
     np.testing.assert_array_equal(ml, ol)
     np.testing.assert_array_equal(md.view(np.uint32), od.view(np.uint32))
     np.testing.assert_array_equal(mc, oc)
+
+
+@pytest.mark.parametrize("device_io", [False, True])
+@pytest.mark.parametrize("force_widen", [0, 1])
+def test_query_begin_end_equals_query(mods, device_io, force_widen):
+    """mmiss_index_query_begin / _end (the wait split off, other GPU work queued in between) returns the bits query() and the
+    oracle return — also when EVERY query goes through the widen pass inside _end (guard_force), behind work the caller
+    queued on the same stream after _begin."""
+    import torch
+    from mmiss_amd import _lib
+
+    FlatIndex, _, _, ro = mods
+    N, D, Q, k = 30000, 512, 40, 10
+    c = _corpus(N, D, seed=61)
+    labels = np.arange(N, dtype=np.int64) * 2 + 5
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    q = _corpus(Q, D, seed=62)
+    ol, od, oc = ro.query(q, ro.normalize_rows(c, "f16"), labels, k)
+    qin = torch.from_numpy(q).cuda() if device_io else q
+    busy = torch.randn(2048, 2048, device="cuda")
+    _lib.set_option("guard_force", force_widen)
+    try:
+        before = idx.guard_stats()["widened"]
+        h = idx.query_begin(qin, k)
+        for _ in range(20):                      # the "next batch's encode": queued behind the first pass, ahead of a widen pass
+            busy = busy @ busy * 1e-3
+        with pytest.raises(RuntimeError, match="still open"):
+            idx.add(c[:4], np.arange(4, dtype=np.int64) + 10 ** 9)
+        with pytest.raises(RuntimeError, match="still open"):
+            idx.query(qin, k)
+        assert idx.count() == N                  # count / labels / guard_stats stay callable
+        lab, dist, cnt = h.result()
+        assert h.result()[0] is lab              # idempotent
+        assert idx.guard_stats()["widened"] - before == (Q if force_widen else 0)
+    finally:
+        _lib.set_option("guard_force", 0)
+    if device_io:
+        assert lab.is_cuda
+        lab, dist, cnt = lab.cpu().numpy(), dist.cpu().numpy(), cnt.cpu().numpy()
+    np.testing.assert_array_equal(lab, ol)
+    np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(cnt, oc)
+    with pytest.raises(RuntimeError, match="no query was begun"):
+        _lib.check(idx._lib.mmiss_index_query_end(idx._h))
+    _check(idx, ro, ro.normalize_rows(c, "f16"), labels, q, k)   # and the index is usable again
+    torch.cuda.synchronize()
