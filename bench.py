@@ -313,7 +313,7 @@ def main():
         # value is the rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE measurement of the SAME command taken in
         # separate --pmc passes and kept in profiles/ — i.e. NOT measured in this run
         traffic, traffic_src = None, None
-        for fn in ("r02_traffic.json", "r01_traffic.json"):
+        for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tj = json.load(f)

@@ -23,12 +23,18 @@ CLASSES = {
     "gemm_bf16_lnfold_qgelu": r"gemm16_kernelIDF16bLi192ELi8E",
     "gemm_bf16_lnfold_bias": r"gemm16_kernelIDF16bLi192ELi7E|gemm256_kernelIDF16bLi7E",
     "gemm_bf16_bias": r"gemm16_kernelIDF16bLi192ELi1E",
+    # round 3: the persistent 256 x 256 kernel (gemm_bf16_p256.h) takes the folded QKV / FC1 GEMMs of the bs-256 step
+    "gemm_bf16_lnfold_qgelu_p256": r"gemm256p_kernelILi8E",
+    "gemm_bf16_lnfold_bias_p256": r"gemm256p_kernelILi7E",
+    "gemm_bf16_bias_qgelu_p256": r"gemm256p_kernelILi2E",
+    "gemm_bf16_bias_p256": r"gemm256p_kernelILi1E",
+    "score_gemm_f16_strip": r"gemm256s_kernelIDF16_",
     "gemm_bf16_patch": r"gemm16_kernelIDF16bLi160ELi4E",
     "score_gemm_f16": r"gemm256_kernelIDF16_Li5E",
     "scan_topk_f16": r"scan_topk_kernelIDF16_",
-    "layernorm": r"layernorm_kernel<true>",
-    "attention": r"attention(_heads)?_kernel<",
-    "im2col": r"im2col_kernel<",
+    "layernorm": r"layernorm_kernel(<true>|ILb1E)",
+    "attention": r"attention(_heads)?_kernel(<|ILi)",
+    "im2col": r"im2col_kernel(<|ILb)",
 }
 ALGORITHMIC = {  # bytes per launch the kernel must move, averaged over the shapes in the class
     # residual GEMM in the folded-LayerNorm mode (the default from 6000 rows): 130.7 MB of GEMM traffic + the bf16 copy of
@@ -38,6 +44,8 @@ ALGORITHMIC = {  # bytes per launch the kernel must move, 
     "gemm_bf16_bias_resid16": 92.7e6,
     "gemm_bf16_bias_resid": 151.6e6, "gemm_bf16_bias_qgelu": 103.0e6, "gemm_bf16_bias": 82.2e6,
     "gemm_bf16_lnfold_qgelu": 104.3e6, "gemm_bf16_lnfold_bias": 83.5e6,
+    # FC1 12800 x 3072 x 768: 19.7 (A) + 4.7 (W) + 78.6 (out) + 1.2 (row statistics) MB; QKV x 2304: 19.7 + 3.5 + 59.0 + 1.2
+    "gemm_bf16_lnfold_qgelu_p256": 104.3e6, "gemm_bf16_lnfold_bias_p256": 83.5e6,
     "scan_topk_f16": 10.24e9,
 }
 
