@@ -52,6 +52,15 @@ int mmiss_dbg_gemm_p256(int device, void* hip_stream, int epi, const void* A, co
                         const float* bias, const float* aux, const float* ln_stats, float ln_eps, int32_t M, int32_t N,
                         int32_t K, int32_t m_valid, int32_t iters, float* ms_per_launch);
 
+/* the residual GEMM on a bf16 residual stream in isolation: out (bf16 [M,N], IN PLACE) = bf16(f32(out) + A W^T + bias),
+ * stats_out (optional) f32 [M][N/64][2] = (sum, sumsq) of the new rows per 64 columns. variant 0 = the 160 x 256 tile on the
+ * staggered loop (csrc/gemm_bf16_p160.h: M % 160 == 0, N % 256 == 0, K % 128 == 0), 128 / 160 / 192 = the 128-column kernel of
+ * that tile height (M a multiple of it). Rows >= m_valid: untouched, except row M - 1 under variant 0. iters > 0 and
+ * ms_per_launch != NULL: HIP-event time of `iters` back-to-back launches (the stream keeps accumulating). */
+int mmiss_dbg_gemm_resid16(int device, void* hip_stream, int variant, const void* A, const void* W, void* out,
+                           const float* bias, float* stats_out, int32_t M, int32_t N, int32_t K, int32_t m_valid,
+                           int32_t iters, float* ms_per_launch);
+
 /* record the residual stream after every layer during encode calls (for mmiss_encoder_tap 0..L) */
 struct mmiss_encoder;
 int mmiss_dbg_encoder_record_taps(struct mmiss_encoder* enc, int on);

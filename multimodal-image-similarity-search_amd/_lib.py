@@ -96,6 +96,7 @@ SIGNATURES = {
     # mmiss_debug.h
     "mmiss_dbg_gemm": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32]),
     "mmiss_dbg_gemm_p256": (_I, [_I, _P, _I, _P, _P, _P, _P, _P, _P, C.c_float, _I32, _I32, _I32, _I32, _I32, _P]),
+    "mmiss_dbg_gemm_resid16": (_I, [_I, _P, _I, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "mmiss_dbg_gemm_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32,
                                  C.POINTER(C.c_float)]),
     "mmiss_dbg_layernorm": (_I, [_I, _P, _P, _P, _P, _P, _I32, _I32, _I32, C.c_float]),

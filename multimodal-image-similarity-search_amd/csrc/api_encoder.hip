@@ -4,6 +4,7 @@
 #include "gemm_bf16.h"
 #include "gemm_bf16_256.h"
 #include "gemm_bf16_p256.h"
+#include "gemm_bf16_p160.h"
 #ifdef MMISS_EXPERIMENTS
 #include "gemm_bf16_ring.h"  // measured-slower alternatives, kept for A/B in debug builds (make EXPERIMENTS=1)
 #endif
@@ -304,6 +305,16 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         if (p256_min == 0 || !gemm256p_ok(epi, padded(256), N, d)) return false;
         return (int64_t)(padded(256) / 256) * (N / 256) >= (p256_min > 1 ? p256_min : 256);
     };
+    // The residual GEMMs on the bf16 stream (out-projection, FC2) on the 160 x 256 tile of the two-phase staggered loop
+    // (gemm_bf16_p160.h, round 3) when that grid is about one round of the chip, or K is long: isolated, ViT-B/32 bs 256
+    // FC2 67.0 -> 61.1 us, out-projection 27.9 -> 25.2, text FC2 47.4 -> 43.0, ViT-L/14 bs 128 FC2 300 -> 274 (its out-projection,
+    // 828 tiles of K = 1024, is faster on the 128-column tile: 93 vs 98 us). Option gemm_p160 = 0 turns it off.
+    const int p160_opt = mmiss_option("gemm_p160", 1);
+    auto p160 = [&](int N, int K) {
+        if (p160_opt == 0 || !gemm160p_ok(padded(160), N, K)) return false;
+        const int64_t tiles = (int64_t)(padded(160) / 160) * (N / 256);
+        return tiles >= 200 && (tiles <= 256 || K >= 2048);
+    };
     // split-K scratch for the narrow long-K GEMM (FC2) while its grid is far below the CU count
     if (gemm_splitk_candidate((int64_t)((M + 127) / 128) * (d / GEMM_BN), tw.mlp))
         MM_TRY(tw.splitk.ensure((size_t)8 * (round_up(M, 128) + 192) * d * 4));  // any tile height's row padding
@@ -427,7 +438,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         ep.stats16 = sfold ? 1 : 0;
         if (resid16) {  // the bf16 rows ARE the residual stream: read-modify-write in place, no f32 stream
             ep.out = tw.xb.p; ep.xb_out = nullptr;
-            MM_TRY(launch_gemm_resid16(st, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
+            if (p160(d, d)) MM_TRY(launch_gemm160p(st, tw.ctx.p, L.wo.p, ep, padded(160), d, d));
+            else MM_TRY(launch_gemm_resid16(st, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         } else {
             MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         }
@@ -487,7 +499,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         ep.splitk_ws = tw.splitk.as<float>(); ep.splitk_ws_bytes = tw.splitk.bytes;
         if (resid16) {
             ep.out = tw.xb.p; ep.xb_out = nullptr;
-            MM_TRY(launch_gemm_resid16(st, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
+            if (p160(d, tw.mlp)) MM_TRY(launch_gemm160p(st, tw.u.p, L.w2.p, ep, padded(160), d, tw.mlp));
+            else MM_TRY(launch_gemm_resid16(st, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         } else {
             MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         }
@@ -1218,6 +1231,37 @@ extern "C" int mmiss_dbg_gemm_p256(int device, void* hip_stream, int epi, const 
     for (int i = 0; i < 3; ++i) MM_TRY(launch_gemm256p(st, epi, A, W, ep, M, N, K));
     MM_HIP(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i) MM_TRY(launch_gemm256p(st, epi, A, W, ep, M, N, K));
+    MM_HIP(hipEventRecord(e1, st));
+    MM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return MMISS_OK;
+}
+
+// the residual GEMM on a bf16 stream (out = bf16(f32(out) + A W^T + bias), in place; stats_out [M][N/64][2] optional) in
+// isolation: variant 0 = the 160 x 256 tile on the staggered loop (gemm160p_kernel), 128 / 160 / 192 = the 128-column kernel
+// with that tile height; iters > 0 also times it (the stream keeps accumulating: only the time means anything then)
+extern "C" int mmiss_dbg_gemm_resid16(int device, void* hip_stream, int variant, const void* A, const void* W, void* out,
+                                      const float* bias, float* stats_out, int32_t M, int32_t N, int32_t K, int32_t m_valid,
+                                      int32_t iters, float* ms_per_launch) {
+    if (!A || !W || !out || !bias) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_gemm_resid16: null pointer");
+    MM_TRY(mmiss_use_device(device));
+    GemmEpi ep{};
+    ep.out = out; ep.bias = bias; ep.ldo = N; ep.m_valid = m_valid; ep.stats_out = stats_out;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    auto run = [&]() -> int {
+        return variant == 0 ? launch_gemm160p(st, A, W, ep, M, N, K) : launch_gemm_resid16(st, variant, A, W, ep, M, N, K);
+    };
+    if (iters <= 0 || !ms_per_launch) return run();
+    hipEvent_t e0, e1;
+    MM_HIP(hipEventCreate(&e0));
+    MM_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) MM_TRY(run());
+    MM_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) MM_TRY(run());
     MM_HIP(hipEventRecord(e1, st));
     MM_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

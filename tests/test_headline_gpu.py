@@ -291,7 +291,8 @@ def test_b32_bs256_bf16_residual_stream_and_the_f32_alternative(b32_256):
     out_i, kern = _kernels_of(lambda: enc.encode_image(px))
     out_t = enc.encode_text(ids)
     np.testing.assert_array_equal(out_i, enc.encode_image(px))
-    assert kern.get("gemm_bf16_bias_resid16_k768", 0) == 11 and kern.get("gemm_bf16_bias_resid16_k3072", 0) == 11, kern
+    # (round 3: out-projection and FC2 of this shape run on the 160 x 256 tile of gemm_bf16_p160.h)
+    assert kern.get("gemm_bf16_bias_resid16_p160_k768", 0) == 11 and kern.get("gemm_bf16_bias_resid16_p160_k3072", 0) == 11, kern
     enc.set_precision("bf16-f32resid")
     try:
         f32_i, kern32 = _kernels_of(lambda: enc.encode_image(px))

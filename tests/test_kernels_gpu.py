@@ -466,3 +466,44 @@ def test_gemm_p256_persistent(env, M, N, K, mv):
             out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
             _p256(env, epi, A, W, out, bias, aux=cvec, stats=stats, m_valid=mv)
             assert torch.allclose(out[:mv].float(), r[:mv], rtol=2 ** -7, atol=4e-3), (epi, rep, (out[:mv].float() - r[:mv]).abs().max())
+
+
+def _resid16(env, variant, A, W, out, bias, stats=None, m_valid=None):
+    torch, _lib, lib = env
+    M, K = A.shape
+    N = W.shape[0]
+    _lib.check(lib.mmiss_dbg_gemm_resid16(0, None, variant, A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr(),
+                                          stats.data_ptr() if stats is not None else None, M, N, K,
+                                          M if m_valid is None else m_valid, 0, None))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,mv", [(12800, 768, 768, 12800), (12800, 768, 3072, 12800), (2560, 768, 768, 2500),
+                                      (19840, 512, 2048, 19712), (160, 256, 256, 160), (6400, 768, 3072, 6400),
+                                      (1280, 1024, 4096, 1280), (33120, 1024, 1024, 33024)])
+def test_gemm_p160_resid16(env, M, N, K, mv):
+    """The 160 x 256 tile on the staggered loop (gemm_bf16_p160.h: out-projection / FC2 on the bf16 residual stream): uneven m
+    halves (48 + 32 rows per wave), filler LDS-DMA pieces, the residual rows prefetched before the K loop, pad rows.
+    Bit-identical to the 128-column kernel of the same epilogue — same k order inside the 16 x 16 x 32 MFMA chain, same
+    bf16 rounding point, same statistics arithmetic — and within bf16 rounding of an fp32 restatement. Repeated with
+    changing inputs to catch a schedule race."""
+    torch, _lib, lib = env
+    g = torch.Generator(device="cuda").manual_seed(7 * M + 3 * N + K)
+    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    for rep in range(3):
+        A = _bf16(torch.randn(M, K, device="cuda", generator=g))
+        x0 = _bf16(torch.randn(M, N, device="cuda", generator=g))
+        ref = x0.float() + (A.float() @ W.float().T + bias)
+        want = x0.clone()
+        st_want = torch.zeros(M, N // 64, 2, device="cuda")
+        _resid16(env, 160, A, W, want, bias, stats=st_want)
+        out = x0.clone()
+        st = torch.full((M, N // 64, 2), float("nan"), device="cuda")
+        _resid16(env, 0, A, W, out, bias, stats=st, m_valid=mv)
+        assert torch.allclose(out[:mv].float(), ref[:mv], rtol=2 ** -7, atol=4e-3), (rep, (out[:mv].float() - ref[:mv]).abs().max())
+        assert torch.equal(out[:mv].view(torch.int16), want[:mv].view(torch.int16)), rep
+        assert torch.equal(st[:mv].view(torch.int32), st_want[:mv].view(torch.int32)), rep
+        if mv < M:   # pad rows: untouched except the dump row M - 1; their statistics are not written
+            assert torch.equal(out[mv:M - 1].view(torch.int16), x0[mv:M - 1].view(torch.int16))
+            assert torch.isnan(st[mv:]).all()

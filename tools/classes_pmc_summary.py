@@ -10,7 +10,8 @@ import sys
 CLASSES = [  # (class, regex over the mangled name, source run)
     ("gemm_bf16_lnfold_qgelu_p256 (FC1)", r"gemm256p_kernelILi8E", "bench"),
     ("gemm_bf16_lnfold_bias_p256 (QKV)", r"gemm256p_kernelILi7E", "bench"),
-    ("gemm_bf16_bias_resid16 (out-proj + FC2)", r"gemm16_kernelIDF16bLi160ELi9E", "bench"),
+    ("gemm_bf16_bias_resid16_p160 (out-proj + FC2)", r"gemm160p_kernel", "bench"),
+    ("gemm_bf16_bias_resid16 (L/14 out-proj, bf16 leg)", r"gemm16_kernelIDF16bLi1[0-9]+ELi9E", "fp8"),
     ("gemm_bf16_patch", r"gemm16_kernelIDF16bLi160ELi4E", "bench"),
     ("attention", r"attention_kernelILi2ELb0E", "bench"),
     ("score_gemm_f16 (step query, 256 x 100k)", r"gemm(256|16)_kernelIDF16_", "bench"),

@@ -18,6 +18,7 @@ import sys
 CLASSES = {
     "gemm_bf16_bias_resid": r"gemm16_kernelIDF16bLi160ELi3E",
     "gemm_bf16_bias_resid16": r"gemm16_kernelIDF16bLi160ELi9E",
+    "gemm_bf16_bias_resid16_p160": r"gemm160p_kernel",   # round 3: out-projection + FC2 of the bs-256 step (gemm_bf16_p160.h)
     "gemm_bf16_bias_resid_pruned": r"gemm16_kernelIDF16bLi128ELi3E",
     "gemm_bf16_bias_qgelu": r"gemm16_kernelIDF16bLi192ELi2E",
     "gemm_bf16_lnfold_qgelu": r"gemm16_kernelIDF16bLi192ELi8E",
@@ -41,7 +42,7 @@ ALGORITHMIC = {  # bytes per launch the kernel must move, 
     # the new residual rows (19.7 MB) + their partial LayerNorm statistics (1.2 MB) that replace the LayerNorm pass
     # bf16 residual stream: out-proj 19.7 (A) + 1.2 (W) + 2 x 19.7 (stream) + 1.2 (stats) = 61.5 MB, FC2 78.6 + 4.7 + 39.3 + 1.2
     # = 123.8 MB -> class average 92.7 MB
-    "gemm_bf16_bias_resid16": 92.7e6,
+    "gemm_bf16_bias_resid16": 92.7e6, "gemm_bf16_bias_resid16_p160": 92.7e6,
     "gemm_bf16_bias_resid": 151.6e6, "gemm_bf16_bias_qgelu": 103.0e6, "gemm_bf16_bias": 82.2e6,
     "gemm_bf16_lnfold_qgelu": 104.3e6, "gemm_bf16_lnfold_bias": 83.5e6,
     # FC1 12800 x 3072 x 768: 19.7 (A) + 4.7 (W) + 78.6 (out) + 1.2 (row statistics) MB; QKV x 2304: 19.7 + 3.5 + 59.0 + 1.2
