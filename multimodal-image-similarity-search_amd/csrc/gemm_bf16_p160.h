@@ -8,11 +8,15 @@
 // stream-K over 256 x 256 tiles lost the operand sharing between neighbouring workgroups and was slower
 // (profiles/gemm_p256_r03.txt, section 9).
 //   * 8 waves as 2 (m) x 4 (n): a wave owns 80 rows x 64 columns = 5 x 4 accumulator blocks of 16 x 16.
-//   * TWO phases per K-tile — [A + W n0 fragment reads, staging, wait] B [20 MFMAs] B [W n1 reads, staging, wait] B [20 MFMAs] B
-//     — not the four of the 256 x 256 tile: its first version here (four phases of 12 / 12 / 8 / 8 MFMAs; 80 rows do not halve
-//     evenly) measured 1.3 us per K-tile for 0.8 us of matrix work, the time of its eight read parts, not of its MFMAs
-//     (FC2 66 us, no better than the 160 x 128 tile). With 20 MFMAs (320 cycles) per phase the partner wave's read part
-//     (14 fragment reads + 3 LDS-DMA pieces) fits beside them.
+//   * TWO phases per K-tile, one per K STEP of 32 columns — [5 A + 4 W fragment reads, staging] B [20 MFMAs] B, twice — with the
+//     two wave halves one barrier apart (one half's read part beside the other's MFMAs). Measured on FC2, us per K-tile net of
+//     the launch's ~12 us of fill, prefetch and epilogue (tools/gemm_p160_ablate.py; the 80 MFMAs alone take 0.58, the 52 KB
+//     of LDS-DMA alone 0.62-0.67, the 36 fragment reads alone 0.29-0.35): the four quadrant phases of the 256 x 256 tile
+//     (12 / 12 / 8 / 8 MFMAs; 80 rows do not halve evenly) 1.3; two staggered phases split by n half (14 + 4 reads) 1.06; these
+//     two (9 + 9 reads) 0.96; an unstaggered form with two fragment sets in registers (a wave reads the next phase's fragments,
+//     then issues this phase's MFMAs) 1.03. Whatever the order, MFMAs + fragment reads take their SUM (0.88 without staging):
+//     on this machine a 1 KB fragment landing in the register file costs the matrix pipe what an MFMA's 1 KB of results
+//     costs it, and an 80 x 64 wave tile needs 9 fragments per 20 MFMAs. FC2 ends at 0.97-0.99 PF instead of 0.90.
 //   * THREE staging buffers of 52 KB (A 160 rows, W n0 / n1 128 rows each), K-tile t+2 staged while t is computed: a K-tile is
 //     ~0.9 us here, two of them in flight (104 KB per CU) keep the prefetch distance of the 256 x 256 loop in time.
 //   * 20 A pieces of 8 rows for 8 waves: every wave issues THREE LDS-DMA operations for the A slot (waves 4-7: two pieces and a
@@ -29,7 +33,9 @@
 #define G160_DUMP (3 * G160_BUF)            // 8 waves x 256 B: where the 4-byte filler pieces land
 #define G160_LDS (G160_DUMP + 2048)         // 161 792 B of the CU's 163 840
 
-template <int VARIANT>  // (a template only so that the header may be included by several translation units)
+// VARIANT (timing experiments, EXPERIMENTS builds, tools/gemm_p160_ablate.py; results are wrong by construction): a mask —
+// 1 = no MFMAs, 2 = no staging, 4 = no fragment reads. 0 = the kernel.
+template <int VARIANT>
 __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W, int M,
                                                           int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dump), 4, lane_vo, so, 0, 0)
 // the A slot of buffer b2 <- K-tile at byte offset ko: THREE operations per wave
 #define G160_STAGE_A(b2, ko)                                                                                 \
-    {                                                                                                       \
+    if constexpr (!((VARIANT & 2) != 0)) {                                                                  \
         char* sl_ = smem + (b2) * G160_BUF + a_dst;                                                         \
         G160_BLDS(srdA, a_so + (ko), sl_);                                                                  \
         G160_BLDS(srdA, a_so + 8 * row8 + (ko), sl_ + 8 * 1024);                                            \
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     }
 // the W slot of n half nq: TWO operations per wave
 #define G160_STAGE_W(b2, nq, ko)                                                                             \
-    {                                                                                                       \
+    if constexpr (!((VARIANT & 2) != 0)) {                                                                  \
         char* sl_ = smem + (b2) * G160_BUF + G160_A_BYTES + (nq) * G160_W_BYTES + w_dst;                    \
         const int so_ = w_so + (nq) * 4 * row8 + (ko);                                                      \
         G160_BLDS(srdW, so_, sl_);                                                                          \
@@ -90,35 +96,34 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
         ab[s] = (wm * 80 + fr) * 128 + sw;
         wb[s] = G160_A_BYTES + (wn * 32 + fr) * 128 + sw;
     }
-    frag am[5][2];
-    frag wq[2][2];
+    frag am[5];
+    frag wq[4];
     f32x4 acc[4][5];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#define G160_READ_A(b)                                                                                       \
-    _Pragma("unroll") for (int mf = 0; mf < 5; ++mf) {                                                      \
-        am[mf][0] = *reinterpret_cast<const frag*>(smem + ab[0] + (b) * G160_BUF + mf * 2048);              \
-        am[mf][1] = *reinterpret_cast<const frag*>(smem + ab[1] + (b) * G160_BUF + mf * 2048);              \
-    }
-#define G160_READ_W(b, nq)                                                                                   \
-    _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                                      \
-        wq[nf][0] = *reinterpret_cast<const frag*>(smem + wb[0] + (b) * G160_BUF + (nq) * G160_W_BYTES + nf * 2048); \
-        wq[nf][1] = *reinterpret_cast<const frag*>(smem + wb[1] + (b) * G160_BUF + (nq) * G160_W_BYTES + nf * 2048); \
-    }
-// the 20 MFMAs of one phase: all five row blocks against the two 16-column blocks of n half nq, k step 0 then k step 1
-#define G160_MMA_HALF(nq, s)                                                                                 \
-    _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                        \
+// the fragments of k step s (32 of the K-tile's 64 columns): five A row blocks, four W column blocks (n0: 0, 1; n1: 2, 3)
+#define G160_READ(b, s)                                                                                      \
+    if constexpr (!((VARIANT & 4) != 0)) {                                                                  \
         _Pragma("unroll") for (int mf = 0; mf < 5; ++mf)                                                    \
-            acc[(nq) * 2 + nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[nf][s], am[mf][s], acc[(nq) * 2 + nf][mf], 0, 0, 0);
-#define G160_MMA(nq)                                                                                         \
-    {                                                                                                       \
+            am[mf] = *reinterpret_cast<const frag*>(smem + ab[s] + (b) * G160_BUF + mf * 2048);             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+            wq[i] = *reinterpret_cast<const frag*>(smem + wb[s] + (b) * G160_BUF + (i >> 1) * G160_W_BYTES + (i & 1) * 2048); \
+    }
+// the 20 MFMAs of one phase: all five row blocks against all four column blocks, one k step
+#define G160_MMA()                                                                                           \
+    if constexpr ((VARIANT & 1) != 0) {                                                                     \
+        _Pragma("unroll") for (int mf = 0; mf < 5; ++mf) asm volatile("" ::"v"(am[mf]));                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(wq[i]));                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+            _Pragma("unroll") for (int mf = 0; mf < 5; ++mf) asm volatile("" : "+v"(acc[i][mf]));           \
+    } else {                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                                      \
-        G160_MMA_HALF(nq, 0)                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
-        G160_MMA_HALF(nq, 1)                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+            _Pragma("unroll") for (int mf = 0; mf < 5; ++mf)                                                \
+                acc[i][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[i], am[mf], acc[i][mf], 0, 0, 0);   \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     }
 #define G160_BARRIER()                            \
@@ -127,29 +132,31 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
         __builtin_amdgcn_s_barrier();             \
         __builtin_amdgcn_sched_barrier(0);        \
     }
-// K-tile t out of buffer B while K-tile t+2 (byte offset ko2) is staged into buffer B2 = (B + 2) % 3, which held K-tile t-1
-// (its A / W n0 slots were last read three barriers ago, its W n1 slot two phases ago — also by the half that runs one
-// barrier behind). A wave issues 7 LDS-DMA operations per K-tile, in the order A A A | W0 W0 W1 W1:
-//   * the wait of phase 0 retires W n1 of THIS K-tile (read in phase 1): younger than it are K-tile t+1's 7 and the 3 just
-//     issued -> vmcnt(10);
-//   * the wait of phase 1 retires A and W n0 of K-tile t+1 (read in its phase 0): younger than W n0 (t+1) are W n1 (t+1): 2,
-//     and K-tile t+2's 7 -> vmcnt(9).
-// Both halves' waits and a barrier precede both halves' reads of what they retire.
+// The half that runs one barrier behind reads a buffer for the last time in the interval right before the other half restages
+// it: its reads must have completed before the barrier between the two.
+#define G160_LATE_READS_DONE() \
+    if (wm == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// K-tile t out of buffer B while K-tile t+2 (byte offset ko2) is staged into buffer B2 = (B + 2) % 3, which held K-tile t-1.
+// The two phases are the two K STEPS of the tile (32 columns each): every read part pulls 9 fragments (5 A + 4 W) and every
+// MFMA part is the full 5 x 4 block. A wave issues 7 LDS-DMA operations per K-tile (A A A in phase 0, W0 W0 W1 W1 in phase
+// 1). All three slots of a K-tile are read from its phase 0 on: the one wait, in phase 1, retires K-tile t+1 completely —
+// younger than it are exactly K-tile t+2's seven: vmcnt(7). Both halves' waits and a barrier precede both halves' reads of
+// what they retire.
 #define G160_KTILE(B, B2)                                                                                    \
     {                                                                                                       \
-        G160_READ_A(B);                                                                                     \
-        G160_READ_W(B, 0);                                                                                  \
+        G160_READ(B, 0);                                                                                    \
         G160_STAGE_A(B2, ko2);                                                                              \
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                                   \
+        G160_LATE_READS_DONE();                                                                             \
         G160_BARRIER();                                                                                     \
-        G160_MMA(0);                                                                                        \
+        G160_MMA();                                                                                         \
         G160_BARRIER();                                                                                     \
-        G160_READ_W(B, 1);                                                                                  \
+        G160_READ(B, 1);                                                                                    \
         G160_STAGE_W(B2, 0, ko2);                                                                           \
         G160_STAGE_W(B2, 1, ko2);                                                                           \
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                    \
+        G160_LATE_READS_DONE();                                                                             \
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                                    \
         G160_BARRIER();                                                                                     \
-        G160_MMA(1);                                                                                        \
+        G160_MMA();                                                                                         \
         G160_BARRIER();                                                                                     \
         if (++k2 == nt) { k2 = 0; ko2 = 0; } else { ko2 += GEMM_BK * 2; }                                   \
     }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     G160_STAGE_W(1, 0, GEMM_BK * 2);
     G160_STAGE_W(1, 1, GEMM_BK * 2);
     ko2 = (nt > 2) ? 2 * GEMM_BK * 2 : 0;   // (K >= 256: nt >= 4)
-    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // A and W n0 of K-tile 0 have landed (younger: its W n1 and K-tile 1's seven)
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // K-tile 0 has landed (younger: K-tile 1's seven)
     G160_BARRIER();
     if (wm == 1) G160_BARRIER();  // the lower half runs one barrier behind from here on
 
@@ -261,11 +268,10 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
 #undef G160_FILL
 #undef G160_STAGE_A
 #undef G160_STAGE_W
-#undef G160_READ_A
-#undef G160_READ_W
-#undef G160_MMA_HALF
+#undef G160_READ
 #undef G160_MMA
 #undef G160_BARRIER
+#undef G160_LATE_READS_DONE
 #undef G160_KTILE
 
 // can the residual GEMM on the bf16 stream run on this tile? (the tile must divide the padded rows / the columns; 32-bit offsets)
@@ -285,6 +291,19 @@ static int launch_gemm160p(hipStream_t st, const void* A, const void* W, const G
     char pname[48];
     snprintf(pname, sizeof(pname), "gemm_bf16_bias_resid16_p160_k%d", K);
     MM_PROF(pname, st, 2.0 * mv * N * K, bytes);
+#ifdef MMISS_EXPERIMENTS
+    const int dbg = mmiss_option("gemm_p160_dbg", 0);
+#define G160_DBG_CASE(D)                                                                                                        \
+    if (dbg == D) {                                                                                                             \
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<D>), G160_LDS));                             \
+        hipLaunchKernelGGL(gemm160p_kernel<D>, dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st,                            \
+                           reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(W), M, N, K, ep);                \
+        MM_HIP(hipGetLastError());                                                                                              \
+        return MMISS_OK;                                                                                                        \
+    }
+    G160_DBG_CASE(1) G160_DBG_CASE(2) G160_DBG_CASE(3) G160_DBG_CASE(4) G160_DBG_CASE(5) G160_DBG_CASE(6) G160_DBG_CASE(7)
+#undef G160_DBG_CASE
+#endif
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<0>), G160_LDS));
     hipLaunchKernelGGL(gemm160p_kernel<0>, dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st, reinterpret_cast<const __bf16*>(A),
                        reinterpret_cast<const __bf16*>(W), M, N, K, ep);
