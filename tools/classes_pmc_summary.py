@@ -1,27 +1,31 @@
 """rocprofv3 --pmc counter_collection.csv files under <dir> -> one CSV row per kernel class: dispatches, the average of every
-counter per dispatch and two ratios — matrix-pipe busy per wave lifetime (SQ_VALU_MFMA_BUSY_CYCLES / SQ_WAVE_CYCLES, both
-quad-cycle counts summed over the waves) and issue-stall share (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)."""
+counter per dispatch and two ratios — the share of the kernel's duration the matrix pipes were busy (SQ_VALU_MFMA_BUSY_CYCLES
+over 1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) and the issue-stall share of the waves' lifetime (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES).
+SQ_INST_CYCLES_VMEM does not exist on gfx950 (rocprofv3: "Missing"): its _RD / _WR halves do, and are collected with
+SQ_INSTS_VMEM_RD / _WR, SQ_ACTIVE_INST_VMEM and the LDS pair in a second pass."""
 import collections
 import csv
 import glob
 import re
 import sys
 
-CLASSES = [  # (class, regex over the mangled name, source run)
-    ("gemm_bf16_lnfold_qgelu_p256 (FC1)", r"gemm256p_kernelILi8E", "bench"),
-    ("gemm_bf16_lnfold_bias_p256 (QKV)", r"gemm256p_kernelILi7E", "bench"),
+CLASSES = [  # (class, regex over the kernel name as rocprofv3 prints it — demangled where its demangler copes —, source run)
+    ("gemm_bf16_lnfold_qgelu_p256 (FC1)", r"gemm256p_kernel(ILi8E|<8,)", "bench"),
+    ("gemm_bf16_lnfold_bias_p256 (QKV)", r"gemm256p_kernel(ILi7E|<7,)", "bench"),
     ("gemm_bf16_bias_resid16_p160 (out-proj + FC2)", r"gemm160p_kernel", "bench"),
-    ("gemm_bf16_bias_resid16 (L/14 out-proj, bf16 leg)", r"gemm16_kernelIDF16bLi1[0-9]+ELi9E", "fp8"),
     ("gemm_bf16_patch", r"gemm16_kernelIDF16bLi160ELi4E", "bench"),
-    ("attention", r"attention_kernelILi2ELb0E", "bench"),
-    ("score_gemm_f16 (step query, 256 x 100k)", r"gemm(256|16)_kernelIDF16_", "bench"),
-    ("gemm_bf16_bias_qgelu_p256 (L/14 FC1, bf16 leg)", r"gemm256p_kernelILi2E", "fp8"),
-    ("gemm_bf16_bias_p256 (L/14 QKV, bf16 leg)", r"gemm256p_kernelILi1E", "fp8"),
+    ("attention (B/32: 50 tokens, 4 heads per workgroup)", r"attention_heads_kernel", "bench"),
+    ("score_gemm_f16 (step query, 256 x 100k)", r"gemm256s_kernelIDF16_|gemm(256|16)_kernelIDF16_", "bench"),
+    ("gemm_bf16_bias_qgelu_p256 (L/14 FC1, bf16 leg)", r"gemm256p_kernel(ILi2E|<2,)", "fp8"),
+    ("gemm_bf16_bias_p256 (L/14 QKV, bf16 leg)", r"gemm256p_kernel(ILi1E|<1,)", "fp8"),
+    ("gemm_bf16_bias_resid16 (L/14 out-proj, both legs)", r"gemm16_kernelIDF16bLi1[0-9]+ELi9E", "fp8"),
+    ("gemm_bf16_bias_resid16_p160 (L/14 FC2, bf16 leg)", r"gemm160p_kernel", "fp8"),
     ("gemm8 (fp8 block-scaled GEMMs, L/14 bs 128)", r"gemm8_kernel", "fp8"),
     ("attention (L/14: 257 tokens)", r"attention", "fp8"),
 ]
-COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INST_CYCLES_VMEM", "SQ_LDS_BANK_CONFLICT",
-            "SQ_WAVE_CYCLES", "SQ_WAVES", "GRBM_GUI_ACTIVE"]
+COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAVES",
+            "GRBM_GUI_ACTIVE", "SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+            "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS"]
 
 
 def load(d):
@@ -37,7 +41,7 @@ def main(root, out):
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["class", "run", "symbols", "dispatches"] + [c + "_per_dispatch" for c in COUNTERS] +
-                   ["mfma_busy_per_wave_cycle", "issue_stall_per_wave_cycle"])
+                   ["matrix_pipe_busy_share_of_kernel_time", "issue_stall_per_wave_cycle"])
         for cls, pat, run in CLASSES:
             rx = re.compile(pat)
             names = [k for k in runs[run] if rx.search(k)]
@@ -49,9 +53,11 @@ def main(root, out):
                 vals = [v for k in names for v in runs[run][k].get(c, [])]
                 avg[c] = sum(vals) / len(vals) if vals else float("nan")
                 n = max(n, len(vals))
-            wc = avg["SQ_WAVE_CYCLES"]
+            # SQ_VALU_MFMA_BUSY_CYCLES: cycles, summed over the SIMDs (= MFMAs x their pass cycles; exact on the GEMMs);
+            # GRBM_GUI_ACTIVE: cycles, summed over the 8 XCDs -> kernel duration in cycles = / 8; 1024 SIMDs on the chip
+            busy = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * avg["GRBM_GUI_ACTIVE"] / 8.0)
             w.writerow([cls, run, len(names), n] + ["%.0f" % avg[c] for c in COUNTERS] +
-                       ["%.3f" % (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / wc), "%.3f" % (avg["SQ_WAIT_INST_ANY"] / wc)])
+                       ["%.3f" % busy, "%.3f" % (avg["SQ_WAIT_INST_ANY"] / avg["SQ_WAVE_CYCLES"])])
 
 
 if __name__ == "__main__":

@@ -10,10 +10,19 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/classes_pmc_$TAG
 mkdir -p $OUT
-SET="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+SET1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+# (SQ_INST_CYCLES_VMEM is not a gfx950 counter: rocprofv3 reports it "Missing"; the family has _RD and _WR halves here:)
+SET2="SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
 SHORT="--steps 5 --warmup 2 --retrieval-rows 0 --no-cpu-baseline --no-kernel-events --no-text"
-rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/bench -o pmc -- python3 bench.py $SHORT > $OUT/bench.log 2>&1
-echo "bench pass rc=$?"
-rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/fp8 -o pmc -- python3 tools/l14_fp8_bench.py > $OUT/fp8.log 2>&1
-echo "fp8 pass rc=$?"
+rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_]*VMEM[A-Z_]*" | sort -u | tr "\n" " " > $OUT/vmem_counters_available.txt
+i=0
+for SET in "$SET1" "$SET2"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/bench/p$i -o pmc -- python3 bench.py $SHORT > $OUT/bench_p$i.log 2>&1
+  echo "bench pass $i rc=$?"
+  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/fp8/p$i -o pmc -- python3 tools/l14_fp8_bench.py > $OUT/fp8_p$i.log 2>&1
+  echo "fp8 pass $i rc=$?"
+done
+grep -h "Missing" $OUT/*.log | sed 's/.*Missing/Missing/' | sort -u
+cat $OUT/vmem_counters_available.txt; echo
 python3 tools/classes_pmc_summary.py $OUT $OUT/summary.csv && cat $OUT/summary.csv

@@ -25,10 +25,10 @@ CLASSES = {
     "gemm_bf16_lnfold_bias": r"gemm16_kernelIDF16bLi192ELi7E|gemm256_kernelIDF16bLi7E",
     "gemm_bf16_bias": r"gemm16_kernelIDF16bLi192ELi1E",
     # round 3: the persistent 256 x 256 kernel (gemm_bf16_p256.h) takes the folded QKV / FC1 GEMMs of the bs-256 step
-    "gemm_bf16_lnfold_qgelu_p256": r"gemm256p_kernelILi8E",
-    "gemm_bf16_lnfold_bias_p256": r"gemm256p_kernelILi7E",
-    "gemm_bf16_bias_qgelu_p256": r"gemm256p_kernelILi2E",
-    "gemm_bf16_bias_p256": r"gemm256p_kernelILi1E",
+    "gemm_bf16_lnfold_qgelu_p256": r"gemm256p_kernel(ILi8E|<8,)",
+    "gemm_bf16_lnfold_bias_p256": r"gemm256p_kernel(ILi7E|<7,)",
+    "gemm_bf16_bias_qgelu_p256": r"gemm256p_kernel(ILi2E|<2,)",
+    "gemm_bf16_bias_p256": r"gemm256p_kernel(ILi1E|<1,)",
     "score_gemm_f16_strip": r"gemm256s_kernelIDF16_",
     "gemm_bf16_patch": r"gemm16_kernelIDF16bLi160ELi4E",
     "score_gemm_f16": r"gemm256_kernelIDF16_Li5E",
