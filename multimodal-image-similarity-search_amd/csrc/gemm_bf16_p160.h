@@ -162,8 +162,8 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     }
 
     // ---- the bf16 rows this wave will add to (its own output rows: nobody else touches them), in the accumulator layout —
-    // 8 bytes per lane and 16 x 16 block, 40 registers — and its bias values: fetched NOW, so that the epilogue of this
-    // one-tile workgroup starts without a memory round trip (ordinary loads beside LDS-DMA: settled before the stream starts)
+    // 8 bytes per lane and 16 x 16 block, 40 registers — and its bias values: requested NOW, in front of the prologue's LDS-DMA,
+    // so that the epilogue of this one-tile workgroup starts without a memory round trip
     u32x2 resid[5][4];
     f32x4 bias[4];
     {
@@ -174,13 +174,6 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
             for (int i = 0; i < 4; ++i) resid[j][i] = *reinterpret_cast<const u32x2*>(ob + (size_t)j * 16 * ep.ldo + i * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias[i] = *reinterpret_cast<const f32x4*>(ep.bias + bn * 256 + wn * 64 + i * 16 + 4 * fg);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(resid[j][i]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(bias[i]));
     }
 
     // prologue: K-tiles 0 and 1 into buffers 0 and 1 (14 operations per wave)
@@ -193,6 +186,14 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     G160_STAGE_W(1, 1, GEMM_BK * 2);
     ko2 = (nt > 2) ? 2 * GEMM_BK * 2 : 0;   // (K >= 256: nt >= 4)
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // K-tile 0 has landed (younger: K-tile 1's seven)
+    // ... and with it the 24 ordinary loads above, which are older: their round trip ran beside the prologue's. Pinned here
+    // so that the compiler's own wait for them sits in front of the K loop, not inside it.
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(resid[j][i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(bias[i]));
     G160_BARRIER();
     if (wm == 1) G160_BARRIER();  // the lower half runs one barrier behind from here on
 
