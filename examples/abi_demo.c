@@ -185,6 +185,20 @@ int main(void) {
     for (int q = 0; q < NIMG; ++q)
         for (int j = 1; j < 10; ++j)
             if (dist[q * 10 + j] < dist[q * 10 + j - 1]) { fprintf(stderr, "distances not ascending\n"); return 1; }
+    {   /* the same query in two halves: between them every mutating call on the handle is refused */
+        int64_t got2[NIMG * 10];
+        float dist2[NIMG * 10];
+        int32_t cnt2[NIMG];
+        const int64_t one = 7;
+        CHECK(mmiss_index_query_begin(idx, emb, NIMG, 10, got2, dist2, cnt2));
+        if (mmiss_index_add(idx, emb, &one, 1) != MMISS_ERR_STATE) { fprintf(stderr, "add inside an open query was not refused\n"); return 1; }
+        CHECK(mmiss_index_query_end(idx));
+        if (memcmp(got, got2, sizeof(got)) || memcmp(dist, dist2, sizeof(dist)) || memcmp(cnt, cnt2, sizeof(cnt))) {
+            fprintf(stderr, "query_begin / query_end differ from query\n");
+            return 1;
+        }
+        if (mmiss_index_query_end(idx) != MMISS_ERR_STATE) { fprintf(stderr, "query_end without query_begin was not refused\n"); return 1; }
+    }
     float blended[2 * 128];
     CHECK(mmiss_blend(0, NULL, emb, temb, 0.5, 2, D, blended));
     if (fabs(row_norm(blended, D) - 1.0) > 1e-5) { fprintf(stderr, "blend is not unit-norm\n"); return 1; }
