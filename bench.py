@@ -224,9 +224,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    drain()
+    last_out = drain()
     fence()
     elapsed = time.perf_counter() - t0
+    # outside the timed region: the last pipelined result against the synchronous query of the same embeddings
+    pipelined_equals_sync = None
+    if world == 1 and last_out is not None:
+        lab_s, dst_s, _c = index.query(emb, K_TOP)
+        pipelined_equals_sync = bool(torch.equal(last_out[0], lab_s) and torch.equal(last_out[1], dst_s))
     _lib.prof_enable(False)
     timed_prof = _lib.prof_read() if dominant else []
     _lib.prof_filter(None, 1)
@@ -631,6 +636,7 @@ def main():
                        "step_pipelining": "one deep: step i+1's encode is queued before the host waits for step i's query results "
                                           "(FlatIndex.query_begin / result()); all K result sets are complete inside the timed region",
                        "ms_per_step_unpipelined": round(unpipelined * 1e3 / args.steps, 3),
+                       "last_pipelined_result_equals_synchronous_query": pipelined_equals_sync,
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
                        "ms_per_step_with_kernel_events": None if events_ms_per_step is None else round(events_ms_per_step, 3)},
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),

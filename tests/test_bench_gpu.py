@@ -35,3 +35,22 @@ def test_bench_two_ranks_gloo_dry_run():
     st = d["stage_ms_max_over_ranks"]
     assert set(st) == {"encode", "all_gather_queries", "local_query", "all_gather_topk", "merge"} and all(v > 0 for v in st.values())
     assert "N-fold" in d["weak_scaling_note"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_one_gpu_pipelined_steps_deliver_the_synchronous_results():
+    """N = 1, the driver's default form with a short run: the timed steps are pipelined one deep (query_begin / query_end);
+    the line says what it did, times the unpipelined form beside it, and its last pipelined result set is the synchronous
+    query's, id for id and bit for bit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--retrieval-rows", "0",
+           "--no-cpu-baseline", "--no-text"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
+    assert "query_begin" in cfg["step_pipelining"] and cfg["ms_per_step_unpipelined"] > 0
+    assert cfg["last_pipelined_result_equals_synchronous_query"] is True
+    assert out["exactness"]["queries"] >= (2 + 3 + 3 + 3) * 256 and out["exactness"]["widened"] == 0
+    assert out["roofline"]["kernel"].startswith("gemm_bf16_") and 0 < out["roofline"]["frac"] < 1
