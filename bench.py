@@ -41,7 +41,8 @@ HBM_PEAK_GBS = 8000.0           # spec; ~6.3 TB/s achievable (same guide)
 KERNEL_SYMBOL = {  # libmmiss kernel class -> symbol as rocprofv3 --kernel-trace prints it
     "gemm_bf16_f32": "gemm16_kernel<__bf16,BM,0>", "gemm_bf16_bias": "gemm16_kernel<__bf16,BM,1>",
     "gemm_bf16_bias_qgelu": "gemm16_kernel<__bf16,BM,2>", "gemm_bf16_bias_resid": "gemm16_kernel<__bf16,BM,3>",
-    "gemm_bf16_bias_resid16": "gemm16_kernel<__bf16,BM,9>", "gemm_bf16_bias_resid16_p160": "gemm160p_kernel<0>",
+    "gemm_bf16_bias_resid16": "gemm16_kernel<__bf16,BM,9>", "gemm_bf16_bias_resid16_p160": "gemm160p_kernel<9,0>",
+    "gemm_bf16_patch_p160": "gemm160p_kernel<4,0>",
     "gemm_bf16_lnfold_bias": "gemm256_kernel<__bf16,7> (>= 85 % tile fill) / gemm16_kernel<__bf16,BM,7>", "gemm_bf16_lnfold_qgelu": "gemm16_kernel<__bf16,BM,8>",
     "gemm_bf16_lnfold_bias_p256": "gemm256p_kernel<7,K/256,0,0>", "gemm_bf16_lnfold_qgelu_p256": "gemm256p_kernel<8,K/256,0,0>",
     "gemm_bf16_bias_p256": "gemm256p_kernel<1,0,0,0>", "gemm_bf16_bias_qgelu_p256": "gemm256p_kernel<2,0,0,0>",

@@ -546,7 +546,14 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
         MM_TRY(tw.splitk.ensure((size_t)8 * Mpp * d * 4));
         ep.splitk_ws = tw.splitk.as<float>(); ep.splitk_ws_bytes = tw.splitk.bytes;
     }
-    MM_TRY(launch_gemm(st, MMISS_EPI_PATCH_F32, bm_p, e->patches.p, e->patch_w.p, ep, Mpp, d, e->Kp));
+    {   // round 3: on the 160 x 256 tile of gemm_bf16_p160.h when that grid is about one round of the chip and K is long
+        const int M160 = (int)round_up(Mpatch, 160);
+        const int64_t tiles = (int64_t)(M160 / 160) * (d / 256);
+        if (mmiss_option("gemm_p160", 1) != 0 && (d % 256) == 0 && gemm160p_ok(M160, d, e->Kp) && tiles >= 200 && tiles <= 256 && e->Kp >= 2048)
+            MM_TRY(launch_gemm160p_patch(st, e->patches.p, e->patch_w.p, ep, M160, d, e->Kp));
+        else
+            MM_TRY(launch_gemm(st, MMISS_EPI_PATCH_F32, bm_p, e->patches.p, e->patch_w.p, ep, Mpp, d, e->Kp));
+    }
     // pre_layrnorm, in place on the fp32 residual stream (HF:modeling_clip.py:640); when the layers will want the bf16 copy
     // and the row statistics of the result (folded LayerNorm, bf16 residual stream) the same pass writes them
     {

@@ -35,7 +35,9 @@
 
 // VARIANT (timing experiments, EXPERIMENTS builds, tools/gemm_p160_ablate.py; results are wrong by construction): a mask —
 // 1 = no MFMAs, 2 = no staging, 4 = no fragment reads. 0 = the kernel.
-template <int VARIANT>
+// EPI: MMISS_EPI_BIAS_RESID_BF16 (the residual GEMMs) or MMISS_EPI_PATCH_F32 (the patch-embedding GEMM: f32 rows scattered to
+// item * tokens + 1 + patch with the position row added, gemm_bf16.h gemm_epilogue's contract; no bias, no residual).
+template <int EPI, int VARIANT>
 __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W, int M,
                                                           int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,9 +166,11 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     // ---- the bf16 rows this wave will add to (its own output rows: nobody else touches them), in the accumulator layout —
     // 8 bytes per lane and 16 x 16 block, 40 registers — and its bias values: requested NOW, in front of the prologue's LDS-DMA,
     // so that the epilogue of this one-tile workgroup starts without a memory round trip
+    constexpr bool RESID = (EPI == MMISS_EPI_BIAS_RESID_BF16);
+    static_assert(RESID || EPI == MMISS_EPI_PATCH_F32, "gemm160p_kernel: epilogue");
     u32x2 resid[5][4];
     f32x4 bias[4];
-    {
+    if constexpr (RESID) {
         const uint16_t* ob = reinterpret_cast<const uint16_t*>(ep.out) + (size_t)(bm * 160 + wm * 80 + fr) * ep.ldo + bn * 256 + wn * 64 + 4 * fg;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
@@ -188,12 +192,14 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // K-tile 0 has landed (younger: K-tile 1's seven)
     // ... and with it the 24 ordinary loads above, which are older: their round trip ran beside the prologue's. Pinned here
     // so that the compiler's own wait for them sits in front of the K loop, not inside it.
+    if constexpr (RESID) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(resid[j][i]));
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(resid[j][i]));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(bias[i]));
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(bias[i]));
+    }
     G160_BARRIER();
     if (wm == 1) G160_BARRIER();  // the lower half runs one barrier behind from here on
 
@@ -206,9 +212,44 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wrap-around staging of the last K-tiles has landed ...
     G160_BARRIER();                // ... on every wave, and every wave has read its last fragments: the buffers are free
 
+    if constexpr (EPI == MMISS_EPI_PATCH_F32) {
+        // f32 rows: 16 rows x 32 columns at a time through the wave's 2 KB patch (16-byte chunks XOR-swizzled by the row), read back
+        // as whole 128-byte row segments; patch row m of the GEMM is token 1 + m % p0 of item m / p0, the position row is added
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int efr = lane_e & 15, efg = lane_e >> 4;
+        const int rrow = lane_e >> 3, rchunk = lane_e & 7;
+        char* patch = smem + wave * 2048;   // (over staging buffer 0)
+        float* outp = reinterpret_cast<float*>(ep.out);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+                    *reinterpret_cast<f32x4*>(patch + efr * 128 + (((ii * 4 + efg) ^ (efr & 7)) << 4)) = acc[2 * h + ii][j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    const int row = rh * 8 + rrow;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * 128 + ((rchunk ^ (row & 7)) << 4));
+                    const int m = bm * 160 + wm * 80 + j * 16 + row;
+                    const int n = bn * 256 + wn * 64 + h * 32 + rchunk * 4;
+                    if (m < ep.m_valid) {
+                        const int img = m / ep.p0, pt = m - img * ep.p0;
+                        const f32x4 pos = *reinterpret_cast<const f32x4*>(ep.aux + (size_t)(1 + pt) * ep.ldo + n);
+                        *reinterpret_cast<f32x4*>(outp + ((size_t)img * ep.p1 + 1 + pt) * ep.ldo + n) = v + pos;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next half
+            }
+        }
+    }
     // ---- epilogue of MMISS_EPI_BIAS_RESID_BF16 (gemm_bf16.h gemm_epilogue: same arithmetic, same statistics, bit for bit),
     // per wave: 5 row blocks x 64 columns through the wave's 2 KB transpose patch, whole 128-byte row segments per store
-    {
+    if constexpr (RESID) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int efr = lane_e & 15, efg = lane_e >> 4;
@@ -296,8 +337,8 @@ static int launch_gemm160p(hipStream_t st, const void* A, const void* W, const G
     const int dbg = mmiss_option("gemm_p160_dbg", 0);
 #define G160_DBG_CASE(D)                                                                                                        \
     if (dbg == D) {                                                                                                             \
-        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<D>), G160_LDS));                             \
-        hipLaunchKernelGGL(gemm160p_kernel<D>, dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st,                            \
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, D>), G160_LDS));                             \
+        hipLaunchKernelGGL((gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, D>), dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st,                            \
                            reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(W), M, N, K, ep);                \
         MM_HIP(hipGetLastError());                                                                                              \
         return MMISS_OK;                                                                                                        \
@@ -305,9 +346,23 @@ static int launch_gemm160p(hipStream_t st, const void* A, const void* W, const G
     G160_DBG_CASE(1) G160_DBG_CASE(2) G160_DBG_CASE(3) G160_DBG_CASE(4) G160_DBG_CASE(5) G160_DBG_CASE(6) G160_DBG_CASE(7)
 #undef G160_DBG_CASE
 #endif
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<0>), G160_LDS));
-    hipLaunchKernelGGL(gemm160p_kernel<0>, dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st, reinterpret_cast<const __bf16*>(A),
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, 0>), G160_LDS));
+    hipLaunchKernelGGL((gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, 0>), dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st, reinterpret_cast<const __bf16*>(A),
                        reinterpret_cast<const __bf16*>(W), M, N, K, ep);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+// The patch-embedding GEMM (MMISS_EPI_PATCH_F32 of gemm_bf16.h: ep.out f32 [items * p1, ldo], ep.aux = position table, ep.p0 = patches
+// per item, ep.p1 = tokens per item) on the same tile: 12 544 patch rows x 768 x 3072 at bs 256 = 79 x 3 tiles.
+static int launch_gemm160p_patch(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
+    if (!gemm160p_ok(M, N, K)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm160p_patch: M=%d N=%d K=%d", M, N, K);
+    if (!ep.out || !ep.aux || ep.p0 <= 0 || ep.p1 <= 0 || ep.ldo < N) MM_FAIL(MMISS_ERR_ARG, "gemm160p_patch: missing operand");
+    const int mv = ep.m_valid < M ? ep.m_valid : M;
+    MM_PROF("gemm_bf16_patch_p160", st, 2.0 * mv * N * K, 2.0 * ((double)mv * K + (double)N * K) + 4.0 * (double)mv * N);
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<MMISS_EPI_PATCH_F32, 0>), G160_LDS));
+    hipLaunchKernelGGL((gemm160p_kernel<MMISS_EPI_PATCH_F32, 0>), dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st,
+                       reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(W), M, N, K, ep);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }

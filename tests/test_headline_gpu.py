@@ -309,6 +309,32 @@ def test_b32_bs256_bf16_residual_stream_and_the_f32_alternative(b32_256):
     assert max(d32) < 6e-5, d32          # (text tower: 3.2e-5 with bf16 operands alone)
 
 
+def test_b32_bs256_the_160x256_tile_is_bit_identical_to_the_128_column_kernels(b32_256):
+    """Round 3: out-projection, FC2 and the patch-embedding GEMM of the bs-256 image encode (and out-projection / FC2 of the
+    256 x 77 text encode) run on the 160 x 256 tile of gemm_bf16_p160.h. Same k order inside every accumulator, same epilogue
+    arithmetic: the embeddings are the SAME BITS as with option gemm_p160 = 0 (the 128-column kernels of rounds 1-2)."""
+    from mmiss_amd import _lib
+
+    enc, small, W, co = b32_256
+    s = co.VIT_B32
+    rng = np.random.Generator(np.random.Philox(79))
+    px = rng.standard_normal((256, 3, 224, 224), dtype=np.float32)
+    ids = co.synthetic_text_ids(256, 77, s.t_vocab, s.eos_token_id, seed=6, bos=49406)
+    out_i, kern = _kernels_of(lambda: enc.encode_image(px))
+    out_t, kern_t = _kernels_of(lambda: enc.encode_text(ids))
+    assert kern.get("gemm_bf16_patch_p160", 0) == 1 and kern.get("gemm_bf16_bias_resid16_p160_k3072", 0) == 11, kern
+    assert kern_t.get("gemm_bf16_bias_resid16_p160_k2048", 0) == 11 and kern_t.get("gemm_bf16_bias_resid16_p160_k512", 0) == 11, kern_t
+    _lib.set_option("gemm_p160", 0)
+    try:
+        old_i, kern0 = _kernels_of(lambda: enc.encode_image(px))
+        old_t = enc.encode_text(ids)
+    finally:
+        _lib.set_option("gemm_p160", 1)
+    assert kern0.get("gemm_bf16_patch", 0) == 1 and kern0.get("gemm_bf16_bias_resid16_k3072", 0) == 11 and not any("p160" in k for k in kern0), kern0
+    np.testing.assert_array_equal(out_i.view(np.uint32), old_i.view(np.uint32))
+    np.testing.assert_array_equal(out_t.view(np.uint32), old_t.view(np.uint32))
+
+
 def test_l14_full_depth_bf16_residual_stream_in_the_separate_layernorm_mode():
     """ViT-L/14 geometry (hidden 1024 > 768: LayerNorm stays a kernel of its own) at 24 images = 6168 token rows, full
     depth: the large-call default keeps the residual stream in bf16 there too (LayerNorm reads the bf16 rows). Against the

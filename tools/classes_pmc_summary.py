@@ -12,14 +12,14 @@ import sys
 CLASSES = [  # (class, regex over the kernel name as rocprofv3 prints it — demangled where its demangler copes —, source run)
     ("gemm_bf16_lnfold_qgelu_p256 (FC1)", r"gemm256p_kernel(ILi8E|<8,)", "bench"),
     ("gemm_bf16_lnfold_bias_p256 (QKV)", r"gemm256p_kernel(ILi7E|<7,)", "bench"),
-    ("gemm_bf16_bias_resid16_p160 (out-proj + FC2)", r"gemm160p_kernel", "bench"),
-    ("gemm_bf16_patch", r"gemm16_kernelIDF16bLi160ELi4E", "bench"),
+    ("gemm_bf16_bias_resid16_p160 (out-proj + FC2)", r"gemm160p_kernel(ILi9E|<9,)", "bench"),
+    ("gemm_bf16_patch_p160", r"gemm160p_kernel(ILi4E|<4,)|gemm16_kernelIDF16bLi160ELi4E", "bench"),
     ("attention (B/32: 50 tokens, 4 heads per workgroup)", r"attention_heads_kernel", "bench"),
     ("score_gemm_f16 (step query, 256 x 100k)", r"gemm256s_kernelIDF16_|gemm(256|16)_kernelIDF16_", "bench"),
     ("gemm_bf16_bias_qgelu_p256 (L/14 FC1, bf16 leg)", r"gemm256p_kernel(ILi2E|<2,)", "fp8"),
     ("gemm_bf16_bias_p256 (L/14 QKV, bf16 leg)", r"gemm256p_kernel(ILi1E|<1,)", "fp8"),
     ("gemm_bf16_bias_resid16 (L/14 out-proj, both legs)", r"gemm16_kernelIDF16bLi1[0-9]+ELi9E", "fp8"),
-    ("gemm_bf16_bias_resid16_p160 (L/14 FC2, bf16 leg)", r"gemm160p_kernel", "fp8"),
+    ("gemm_bf16_bias_resid16_p160 (L/14 FC2, bf16 leg)", r"gemm160p_kernel(ILi9E|<9,)", "fp8"),
     ("gemm8 (fp8 block-scaled GEMMs, L/14 bs 128)", r"gemm8_kernel", "fp8"),
     ("attention (L/14: 257 tokens)", r"attention", "fp8"),
 ]

@@ -18,7 +18,8 @@ import sys
 CLASSES = {
     "gemm_bf16_bias_resid": r"gemm16_kernelIDF16bLi160ELi3E",
     "gemm_bf16_bias_resid16": r"gemm16_kernelIDF16bLi160ELi9E",
-    "gemm_bf16_bias_resid16_p160": r"gemm160p_kernel",   # round 3: out-projection + FC2 of the bs-256 step (gemm_bf16_p160.h)
+    "gemm_bf16_bias_resid16_p160": r"gemm160p_kernel(ILi9E|<9,)",   # round 3: out-projection + FC2 of the bs-256 step (gemm_bf16_p160.h)
+    "gemm_bf16_patch_p160": r"gemm160p_kernel(ILi4E|<4,)",
     "gemm_bf16_bias_resid_pruned": r"gemm16_kernelIDF16bLi128ELi3E",
     "gemm_bf16_bias_qgelu": r"gemm16_kernelIDF16bLi192ELi2E",
     "gemm_bf16_lnfold_qgelu": r"gemm16_kernelIDF16bLi192ELi8E",

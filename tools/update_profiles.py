@@ -42,14 +42,14 @@ ktot = sum(float(x["TotalDurationNs"]) for x in stats if "at::native" not in x["
 r, l, c = d["retrieval"], d["l14"], d["cpu_baseline"]
 q1, qk, f = r["Q1"], r["Q1024"], l["fp8"]
 rows = [("folded FC1 `gemm256p_kernel<8,3,0,0>` (persistent 256²)", "gemm_bf16_lnfold_qgelu_p256", r"gemm256p_kernel(ILi8E|<8,)", "gemm_bf16_lnfold_qgelu_p256"),
-        ("FC2 on the bf16 stream `gemm160p_kernel<0>` (160 × 256, one round)", "gemm_bf16_bias_resid16_p160_k3072", None, "gemm_bf16_bias_resid16_p160"),
+        ("FC2 on the bf16 stream `gemm160p_kernel<9,0>` (160 × 256, one round)", "gemm_bf16_bias_resid16_p160_k3072", None, "gemm_bf16_bias_resid16_p160"),
         ("folded QKV `gemm256p_kernel<7,3,0,0>`", "gemm_bf16_lnfold_bias_p256", r"gemm256p_kernel(ILi7E|<7,)", "gemm_bf16_lnfold_bias_p256"),
-        ("out-projection `gemm160p_kernel<0>`", "gemm_bf16_bias_resid16_p160_k768", None, "gemm_bf16_bias_resid16_p160"),
+        ("out-projection `gemm160p_kernel<9,0>`", "gemm_bf16_bias_resid16_p160_k768", None, "gemm_bf16_bias_resid16_p160"),
         ("`attention_heads_kernel<2,false,4>`", "attention", r"attention_heads_kernel", "attention")]
 table = ""
 for label, kname, rx, tcls in rows:
     k = K[kname]
-    prof = f"{rp(rx):.1f}" if rx else f"class average {rp('gemm160p_kernel'):.1f}"
+    prof = f"{rp(rx):.1f}" if rx else f"class average {rp('gemm160p_kernel(ILi9E|<9,)'):.1f}"
     t = T.get(tcls, {})
     ratio = f"{t['traffic_bytes'] / 1e6:.0f} MB" + (f" = {t['ratio_to_algorithmic']:.2f} ×" if "ratio_to_algorithmic" in t else "")
     mfma = pm(kname.split("_k")[0] if "p160" in kname else kname, "matrix_pipe_busy_share_of_kernel_time")
