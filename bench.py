@@ -734,6 +734,35 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
                               "hbm_gbs_equiv": round(N8 * D8 * 2 / dt / 1e9, 1)}
         idx8.close()
         res["shard_50Mx768"] = shard
+        # the same 10M x 512 rows stored as fp8 (MMISS_F8: e4m3 codes of 128 x, half the bytes of f16 per row), N = 1 only,
+        # informational: exact with respect to its stored rows, which are 2^-4-coarse (include/mmiss.h)
+        idxf = FlatIndex(D, "f8", device=local_rank, capacity=N)
+        gen8 = torch.Generator(device=dev).manual_seed(4 + rank)
+        for r0 in range(0, N, chunk):
+            n = min(chunk, N - r0)
+            idxf.add(torch.randn(n, D, device=dev, generator=gen8), np.arange(r0, r0 + n, dtype=np.int64))
+        f8 = {"rows": N, "dim": D, "dtype": "f8 (e4m3 x 2^7)", "k": K_TOP}
+        for Q, iters in ((1, 20), (16, 10)):
+            q = torch.randn(Q, D, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+            idxf.query(q, K_TOP)
+            torch.cuda.synchronize()
+            _lib.prof_reset()
+            _lib.prof_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                idxf.query(q, K_TOP)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / iters
+            _lib.prof_enable(False)
+            sc = {p["kernel"]: p for p in _lib.prof_read()}.get("scan_topk_f8")
+            f8[f"Q{Q}"] = {"ms_per_batch": round(dt * 1e3, 3), "mvec_per_s": round(N / dt / 1e6, 1)}
+            if sc:
+                sms = sc["ms"] / sc["launches"]
+                f8[f"Q{Q}"]["scan_kernel"] = {"avg_ms": round(sms, 4), "hbm_gbs": round(N * D / sms / 1e6, 1),
+                                              "hbm_frac": round(N * D / sms / 1e6 / HBM_PEAK_GBS, 4)}
+        f8["exactness"] = idxf.guard_stats()
+        idxf.close()
+        res["f8_rows"] = f8
     return res
 
 

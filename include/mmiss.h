@@ -43,8 +43,12 @@ enum {
     MMISS_ERR_IO = -6           /* file read/write failed (index save/load)          */
 };
 
-/* index storage dtypes */
-enum { MMISS_F32 = 0, MMISS_F16 = 1 };
+/* index storage dtypes. MMISS_F8: one byte per element, OCP e4m3 with the fixed scale 2^7 — a stored element is
+ * decode(byte) / 128; a unit-norm row has |x_i| <= 1, so 128 x_i fits e4m3 and a typical component keeps its 3 mantissa bits.
+ * Distances are exact (canonical fp64) with respect to the STORED rows, as for f16; the stored rows themselves are 2^-4-coarse,
+ * so an fp8 index ranks like the f32 / f16 one only up to that quantisation (~1e-2 in cosine). Queries of any batch size
+ * take the streaming scan (half the bytes of f16 per row), not the score-GEMM path. */
+enum { MMISS_F32 = 0, MMISS_F16 = 1, MMISS_F8 = 2 };
 
 typedef struct mmiss_encoder mmiss_encoder;
 typedef struct mmiss_index mmiss_index;
@@ -174,7 +178,7 @@ int mmiss_encoder_tap(mmiss_encoder* enc, int tower, int what, float* out, int64
 
 /* ---------------------------------------------------------------- flat index ------------------- */
 /*
- * Flat cosine index resident in HBM: rows are L2-normalised at add time and stored as f32 or f16.
+ * Flat cosine index resident in HBM: rows are L2-normalised at add time and stored as f32, f16 or fp8 (e4m3).
  * replaces chromadb's collection with metadata {"hnsw:space":"cosine"} — backend/app/utils.py:104-137
  */
 int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device, int64_t capacity_hint, mmiss_index** out);

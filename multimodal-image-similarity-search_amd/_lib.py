@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmiss.so")
 MMISS_OK = 0
 MMISS_F32 = 0
 MMISS_F16 = 1
+MMISS_F8 = 2
 MMISS_PREC_BF16 = 0
 MMISS_PREC_FP8 = 1
 MMISS_PREC_BF16_F32RESID = 2

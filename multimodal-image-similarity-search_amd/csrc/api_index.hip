@@ -9,6 +9,7 @@
 
 struct mmiss_index {
     int dim = 0, dtype = MMISS_F32, device = 0, elt = 4;
+    int qelt() const { return dtype == MMISS_F32 ? 4 : 2; }   // bytes per element of the scan's query operand (f16 for f16 and fp8 rows)
     hipStream_t own_stream = nullptr, user_stream = nullptr;
     bool has_user_stream = false;
     // a call that returns with work still queued on a caller's stream (device outputs) marks its end with this event;
@@ -81,6 +82,8 @@ int launch_normalize(mmiss_index* ix, const float* src_dev, void* dst, int64_t n
     const int grid = (int)((n + 3) / 4);
     if (ix->dtype == MMISS_F16)
         hipLaunchKernelGGL(normalize_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, src_dev, (_Float16*)dst, n, ix->dim);
+    else if (ix->dtype == MMISS_F8)
+        hipLaunchKernelGGL(normalize_rows_kernel<F8>, dim3(grid), dim3(256), 0, st, src_dev, (F8*)dst, n, ix->dim);
     else
         hipLaunchKernelGGL(normalize_rows_kernel<float>, dim3(grid), dim3(256), 0, st, src_dev, (float*)dst, n, ix->dim);
     MM_HIP(hipGetLastError());
@@ -146,7 +149,12 @@ ScanPlan plan_scan(int D, int elt, int Q, int kp, int64_t N) {
 int launch_scan(mmiss_index* ix, hipStream_t st, const ScanArgs& a, const ScanPlan& p) {
     const double flops = 2.0 * a.Q * (double)a.N * a.D;
     const double bytes = (double)a.N * a.D * ix->elt;
-    MM_PROF(ix->dtype == MMISS_F16 ? "scan_topk_f16" : "scan_topk_f32", st, flops, bytes);
+    MM_PROF(ix->dtype == MMISS_F16 ? "scan_topk_f16" : ix->dtype == MMISS_F8 ? "scan_topk_f8" : "scan_topk_f32", st, flops, bytes);
+    if (ix->dtype == MMISS_F8) {
+        if (p.nqt == 1) return launch_scan_t<F8, 1, 64>(st, a, p.slabs, p.qtiles, p.lds);
+        if (p.nqt == 2) return launch_scan_t<F8, 2, 32>(st, a, p.slabs, p.qtiles, p.lds);
+        return launch_scan_t<F8, 4, 32>(st, a, p.slabs, p.qtiles, p.lds);
+    }
     if (ix->dtype == MMISS_F16) {
         if (p.nqt == 1) {
             if (mmiss_option("scan_group", 8) == 16) return launch_scan_t<_Float16, 1, 64, 16>(st, a, p.slabs, p.qtiles, p.lds);
@@ -192,11 +200,12 @@ extern "C" int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device
                                   mmiss_index** out) {
     if (!out) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_create: null out");
     if (dim <= 0 || dim % 128 || dim > 4096) MM_FAIL(MMISS_ERR_UNSUPPORTED, "index dim %d: need a multiple of 128, <= 4096", dim);
-    if (storage_dtype != MMISS_F32 && storage_dtype != MMISS_F16) MM_FAIL(MMISS_ERR_ARG, "unknown storage dtype %d", storage_dtype);
+    if (storage_dtype != MMISS_F32 && storage_dtype != MMISS_F16 && storage_dtype != MMISS_F8)
+        MM_FAIL(MMISS_ERR_ARG, "unknown storage dtype %d", storage_dtype);
     MM_TRY(mmiss_use_device(device));
     mmiss_index* ix = new (std::nothrow) mmiss_index();
     if (!ix) MM_FAIL(MMISS_ERR_NOMEM, "out of host memory");
-    ix->dim = dim; ix->dtype = storage_dtype; ix->device = device; ix->elt = storage_dtype == MMISS_F16 ? 2 : 4;
+    ix->dim = dim; ix->dtype = storage_dtype; ix->device = device; ix->elt = storage_dtype == MMISS_F16 ? 2 : storage_dtype == MMISS_F8 ? 1 : 4;
     if (hipStreamCreateWithFlags(&ix->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ix;
         MM_FAIL(MMISS_ERR_HIP, "hipStreamCreate failed");
@@ -368,6 +377,9 @@ extern "C" int mmiss_index_remove(mmiss_index* ix, const int64_t* labels, int64_
         if (ix->dtype == MMISS_F16)
             hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.as<_Float16>(),
                                ix->map.as<int64_t>(), nr.as<_Float16>(), keep, ix->dim);
+        else if (ix->dtype == MMISS_F8)
+            hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, ix->rows.as<uint8_t>(),
+                               ix->map.as<int64_t>(), nr.as<uint8_t>(), keep, ix->dim);
         else
             hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.as<float>(),
                                ix->map.as<int64_t>(), nr.as<float>(), keep, ix->dim);
@@ -404,6 +416,9 @@ extern "C" int mmiss_index_get(mmiss_index* ix, const int64_t* labels, int64_t n
     const int grid = (int)std::min<int64_t>(4096, (n * ix->dim + 255) / 256);
     if (ix->dtype == MMISS_F16)
         hipLaunchKernelGGL(gather_rows_f32_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.as<_Float16>(),
+                           ix->map.as<int64_t>(), dst, n, ix->dim);
+    else if (ix->dtype == MMISS_F8)
+        hipLaunchKernelGGL(gather_rows_f32_kernel<F8>, dim3(grid), dim3(256), 0, st, ix->rows.as<F8>(),
                            ix->map.as<int64_t>(), dst, n, ix->dim);
     else
         hipLaunchKernelGGL(gather_rows_f32_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.as<float>(),
@@ -443,6 +458,9 @@ double guard_eps(const mmiss_index* ix) {
     const double D = ix->dim;
     double e = 4.0 * D * ldexp(1.0, -24);
     if (ix->dtype == MMISS_F16) e += ldexp(1.0, -11) + D * ldexp(1.0, -25);
+    // fp8 rows: the scan's row operand is exact (e4m3 codes widen exactly to f16) and the query operand is rounded to f16 as
+    // above; a stored row's norm is within (1 + 2^-4) of 1 (three mantissa bits per component)
+    if (ix->dtype == MMISS_F8) e += ldexp(1.0, -11) * 1.07 + D * ldexp(1.0, -25);
     return e * 1.003 + ldexp(1.0, -21);
 }
 
@@ -454,6 +472,8 @@ int launch_rerank(mmiss_index* ix, hipStream_t st, const RerankArgs& r, int bloc
     const int threads = r.ncand >= 16 ? 1024 : 256;  // one wave per candidate row: more waves hide the gather latency
     if (ix->dtype == MMISS_F16)
         hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(blocks), dim3(threads), lds, st, r);
+    else if (ix->dtype == MMISS_F8)
+        hipLaunchKernelGGL(rerank_kernel<F8>, dim3(blocks), dim3(threads), lds, st, r);
     else
         hipLaunchKernelGGL(rerank_kernel<float>, dim3(blocks), dim3(threads), lds, st, r);
     MM_HIP(hipGetLastError());
@@ -490,6 +510,9 @@ int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_
             const int grid = (int)std::min<int64_t>(8192, (N + 15) / 16);
             if (ix->dtype == MMISS_F16)
                 hipLaunchKernelGGL(canonical_scan_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
+                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
+            else if (ix->dtype == MMISS_F8)
+                hipLaunchKernelGGL(canonical_scan_kernel<F8>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
                                    ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
             else
                 hipLaunchKernelGGL(canonical_scan_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
@@ -533,7 +556,7 @@ int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
     std::vector<int64_t> map64(which.begin(), which.end());
     MM_TRY(ix->qmap.ensure((size_t)Qf * 4));
     MM_TRY(ix->qmap64.ensure((size_t)Qf * 8));
-    MM_TRY(ix->qs2.ensure((size_t)Qfp * D * ix->elt));
+    MM_TRY(ix->qs2.ensure((size_t)Qfp * D * ix->qelt()));
     MM_TRY(ix->cand2.ensure((size_t)Qf * CAPF * 4));
     MM_TRY(ix->cur2_s.ensure((size_t)Qf * 4));
     MM_TRY(ix->cur2_r.ensure((size_t)Qf * 4));
@@ -543,11 +566,11 @@ int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
     MM_HIP(hipMemcpyAsync(ix->qmap64.p, map64.data(), (size_t)Qf * 8, hipMemcpyHostToDevice, st));
     MM_HIP(hipMemcpyAsync(ix->cur2_s.p, inf.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
     MM_HIP(hipMemcpyAsync(ix->cur2_r.p, neg.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
-    MM_HIP(hipMemsetAsync(ix->qs2.p, 0, (size_t)Qfp * D * ix->elt, st));
+    MM_HIP(hipMemsetAsync(ix->qs2.p, 0, (size_t)Qfp * D * ix->qelt(), st));
     MM_HIP(hipMemsetAsync(ix->cand2.p, 0xff, (size_t)Qf * CAPF * 4, st));  // all -1
     {
         const int grid = (int)std::min<int64_t>(4096, ((int64_t)Qf * D + 255) / 256);
-        if (ix->dtype == MMISS_F16)
+        if (ix->dtype != MMISS_F32)   // (f16 query operand for f16 and fp8 rows)
             hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->qs.as<_Float16>(),
                                ix->qmap64.as<int64_t>(), ix->qs2.as<_Float16>(), (int64_t)Qf, D);
         else
@@ -556,7 +579,7 @@ int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
         MM_HIP(hipGetLastError());
     }
     MM_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
-    const ScanPlan p = plan_scan(D, ix->elt, Qf, KP, N);
+    const ScanPlan p = plan_scan(D, ix->qelt(), Qf, KP, N);
     MM_TRY(ix->lists_s.ensure((size_t)p.slabs * Qf * KP * 4));
     MM_TRY(ix->lists_r.ensure((size_t)p.slabs * Qf * KP * 4));
     const int pmax = (CAPF - kkpad) / KP;
@@ -658,11 +681,11 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         qsrc = ix->qstage.as<float>();
     }
     MM_TRY(ix->qn.ensure((size_t)Qpad * D * 4));
-    MM_TRY(ix->qs.ensure((size_t)Qpad * D * ix->elt));
+    MM_TRY(ix->qs.ensure((size_t)Qpad * D * ix->qelt()));
     {
         MM_PROF("prep_queries", st, 4.0 * Q * D, (double)Q * D * (8 + ix->elt));
         const int grid = (Qpad + 3) / 4;
-        if (ix->dtype == MMISS_F16)
+        if (ix->dtype != MMISS_F32)   // (f16 query operand for f16 and fp8 rows)
             hipLaunchKernelGGL(prep_queries_kernel<_Float16>, dim3(grid), dim3(256), 0, st, qsrc, ix->qn.as<float>(),
                                ix->qs.as<_Float16>(), Q, Qpad, D);
         else
@@ -800,7 +823,7 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         m.cur_s = ix->cur_s.as<float>(); m.cur_r = ix->cur_r.as<int32_t>();  // k'-th group maximum
         MM_TRY(launch_merge(ix, st, m));
     } else {
-        const ScanPlan p = plan_scan(D, ix->elt, Q, kp, N);
+        const ScanPlan p = plan_scan(D, ix->qelt(), Q, kp, N);
         MM_TRY(ix->lists_s.ensure((size_t)p.slabs * Q * kp * 4));
         MM_TRY(ix->lists_r.ensure((size_t)p.slabs * Q * kp * 4));
         const bool paging = pages > 1;

@@ -29,6 +29,24 @@ __device__ __forceinline__ double wave_butterfly_sum(double v) {
     return v;
 }
 
+// fp8 storage (OCP e4m3) with the FIXED scale 2^7: a unit-norm row has |x_i| <= 1, so 128 x_i fits e4m3 (largest value 448) and
+// a component of typical size 1/sqrt(D) keeps its three mantissa bits; the stored VALUE is decode(byte) / 128, exactly
+// representable in f16 and f32 (oracle/retrieval_oracle.py normalize_rows(.., "f8") restates the same rounding).
+#define MMISS_F8_SCALE 128.0f
+struct F8 {
+    uint8_t b;
+    F8() = default;
+    __device__ explicit F8(float y) { b = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(y * MMISS_F8_SCALE, 0.0f, 0, false) & 0xff); }
+    __device__ explicit operator float() const { return __builtin_amdgcn_cvt_f32_fp8((int)b, 0) * (1.0f / MMISS_F8_SCALE); }
+};
+// four consecutive codes of a row -> their values
+__device__ __forceinline__ void f8x4_values(uint32_t w, float (&v)[4]) {
+    v[0] = __builtin_amdgcn_cvt_f32_fp8((int)w, 0) * (1.0f / MMISS_F8_SCALE);
+    v[1] = __builtin_amdgcn_cvt_f32_fp8((int)w, 1) * (1.0f / MMISS_F8_SCALE);
+    v[2] = __builtin_amdgcn_cvt_f32_fp8((int)w, 2) * (1.0f / MMISS_F8_SCALE);
+    v[3] = __builtin_amdgcn_cvt_f32_fp8((int)w, 3) * (1.0f / MMISS_F8_SCALE);
+}
+
 template <typename T> __device__ __forceinline__ double widen(T v) { return (double)(float)v; }
 
 // ------------------------------------------------------------------------------------------------
@@ -143,8 +161,11 @@ __device__ __forceinline__ void wave_sort64(float& s, int& r, int lane) {
 // lives in a register.
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct ScanTraits;
-template <> struct ScanTraits<_Float16> { static constexpr int ELT = 2; };
-template <> struct ScanTraits<float> { static constexpr int ELT = 4; };
+// ELT = bytes per stored element, QELT = bytes per element of the query operand (f16 for f16 AND fp8 rows: the codes widen
+// exactly to f16 in registers), SCORE_SCALE = what the accumulated dot product of the raw operands is multiplied by
+template <> struct ScanTraits<_Float16> { static constexpr int ELT = 2, QELT = 2; static constexpr float SCORE_SCALE = 1.0f; };
+template <> struct ScanTraits<float> { static constexpr int ELT = 4, QELT = 4; static constexpr float SCORE_SCALE = 1.0f; };
+template <> struct ScanTraits<F8> { static constexpr int ELT = 1, QELT = 2; static constexpr float SCORE_SCALE = 1.0f / MMISS_F8_SCALE; };
 
 struct ScanArgs {
     const void* rows;     // [N, D] storage dtype
@@ -190,9 +211,9 @@ __device__ __forceinline__ u32x4 scan_row_load(const u32x4* p) {
 template <typename T, int NQT, int CAP, int GS = 8>
 __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ELT = ScanTraits<T>::ELT;
+    constexpr int ELT = ScanTraits<T>::ELT, QELT = ScanTraits<T>::QELT;
     constexpr int NQ = 16 * NQT;
-    const ScanLds<NQT, CAP> L(a.D, ELT);
+    const ScanLds<NQT, CAP> L(a.D, QELT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int qbase = blockIdx.y * NQ;
@@ -206,8 +227,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
 
     // stage the query block (16-byte chunks), init list state
     {
-        const int chunks_per_row = D * ELT / 16;
-        const char* qsrc = reinterpret_cast<const char*>(a.qs) + (size_t)qbase * D * ELT;
+        const int chunks_per_row = D * QELT / 16;
+        const char* qsrc = reinterpret_cast<const char*>(a.qs) + (size_t)qbase * D * QELT;
         for (int i = tid; i < NQ * chunks_per_row; i += 256) {
             const int qr = i / chunks_per_row, c = i - qr * chunks_per_row;
             *reinterpret_cast<u32x4*>(sQ + qr * L.qstride + c * 16) =
@@ -260,8 +281,9 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
         f32x4 acc[NQT];
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // 64 bytes of every row per step (4 lanes x 16 B); steps are issued in groups of 8 (then 4) with all
-        // the group's global loads ahead of its MFMAs, so 8 (4) 1-KiB wave-loads are in flight per wave
+        // f16 / f32 rows: 64 bytes of every row per step (4 lanes x 16 B: 32 f16 or 16 f32 elements of k); steps are issued
+        // in groups of 8 (then 4) with all the group's global loads ahead of its MFMAs, so 8 (4) 1-KiB wave-loads are in
+        // flight per wave
         auto steps = [&](auto nsteps_tag, int byte0) {
             constexpr int NS = decltype(nsteps_tag)::value;
             u32x4 araw[NS];
@@ -284,12 +306,55 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
                 }
             }
         };
-        const int row_bytes = D * ELT;  // a multiple of 256 (checked on the host)
-        int byte0 = 0;
-        if constexpr (GS == 16)
-            for (; byte0 + 1024 <= row_bytes; byte0 += 1024) steps(std::integral_constant<int, 16>{}, byte0);
-        for (; byte0 + 512 <= row_bytes; byte0 += 512) steps(std::integral_constant<int, 8>{}, byte0);
-        if (byte0 < row_bytes) steps(std::integral_constant<int, 4>{}, byte0);
+        // fp8 rows: a lane loads SIXTEEN codes (16 bytes: whole 64-byte row segments per four lanes, as the f16 scan — with
+        // 8-byte loads the scan was bound by requests, 4.5 TB/s) and feeds two MFMAs from them. Lane group fg therefore
+        // holds k = 16 fg .. 16 fg + 15 of a 64-wide span, not 8 fg .. + 7 of two 32-wide steps: a permutation of k inside
+        // the span, applied to the query fragment as well (it only changes the order in which the APPROXIMATE score is
+        // summed; the guard's bound does not depend on it and the returned distances are canonical).
+        auto spans = [&](auto nsp_tag, int span0) {
+            constexpr int NS = decltype(nsp_tag)::value;
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const char* rp8 = reinterpret_cast<const char*>(a.rows) + (size_t)rload * D + fg * 16;
+            const char* qp8 = sQ + fr * L.qstride + fg * 32;
+            u32x4 araw[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) araw[s] = scan_row_load(reinterpret_cast<const u32x4*>(rp8 + (span0 + s) * 64));
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f16x8 a16;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const f2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)araw[s][2 * h + w], false);
+                        const f2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)araw[s][2 * h + w], true);
+                        const h2 l2 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(lo[0], lo[1]));   // (exact: e4m3 fits f16)
+                        const h2 g2 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(hi[0], hi[1]));
+                        a16[4 * w + 0] = l2[0]; a16[4 * w + 1] = l2[1]; a16[4 * w + 2] = g2[0]; a16[4 * w + 3] = g2[1];
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < NQT; ++qt) {
+                        const u32x4 braw = *reinterpret_cast<const u32x4*>(qp8 + qt * 16 * L.qstride + (span0 + s) * 128 + h * 16);
+                        acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16, __builtin_bit_cast(f16x8, braw), acc[qt], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        if constexpr (ELT == 1) {
+            const int nspans = D >> 6;   // D % 128 == 0: even
+            int sp = 0;
+            for (; sp + 8 <= nspans; sp += 8) spans(std::integral_constant<int, 8>{}, sp);
+            if (sp + 4 <= nspans) { spans(std::integral_constant<int, 4>{}, sp); sp += 4; }
+            if (sp < nspans) spans(std::integral_constant<int, 2>{}, sp);
+        } else {
+            const int row_bytes = D * QELT;  // of a QUERY row: a multiple of 256 (index dim % 128 == 0; f32: % 64)
+            int byte0 = 0;
+            if constexpr (GS == 16)
+                for (; byte0 + 1024 <= row_bytes; byte0 += 1024) steps(std::integral_constant<int, 16>{}, byte0);
+            for (; byte0 + 512 <= row_bytes; byte0 += 512) steps(std::integral_constant<int, 8>{}, byte0);
+            if (byte0 < row_bytes) steps(std::integral_constant<int, 4>{}, byte0);
+        }
         // filter + append
         bool need = false;
 #pragma unroll
@@ -299,7 +364,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int64_t row = row0 + 4 * fg + reg;
-                const float s = acc[qt][reg];
+                const float s = acc[qt][reg] * ScanTraits<T>::SCORE_SCALE;   // (a power of two: exact)
                 const int ri = (int)row;
                 const bool after = (s < cur_s[qt]) || (s == cur_s[qt] && ri > cur_r[qt]);
                 if (qok && row < a.N && s > tau_r[qt] && after) {
@@ -672,7 +737,11 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
         for (int d0 = 0; d0 < a.D; d0 += 64) {
             const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + d0);
             float rr[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (sizeof(T) == 1) {
+                uint32_t w = 0u;   // (code 0 = +0.0)
+                if (live) w = *reinterpret_cast<const uint32_t*>(rv + d0);
+                f8x4_values(w, rr);
+            } else if constexpr (sizeof(T) == 2) {
                 u32x2 w = u32x2{0u, 0u};
                 if (live) w = *reinterpret_cast<const u32x2*>(rv + d0);
                 const _Float16* h = reinterpret_cast<const _Float16*>(&w);
@@ -772,7 +841,11 @@ __global__ __launch_bounds__(256) void canonical_scan_kernel(const void* __restr
         for (int d0 = 0; d0 < D; d0 += 64) {
             const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + d0);
             float rr[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (sizeof(T) == 1) {
+                uint32_t w = 0u;   // (code 0 = +0.0)
+                if (live) w = *reinterpret_cast<const uint32_t*>(rv + d0);
+                f8x4_values(w, rr);
+            } else if constexpr (sizeof(T) == 2) {
                 u32x2 w = u32x2{0u, 0u};
                 if (live) w = *reinterpret_cast<const u32x2*>(rv + d0);
                 const _Float16* h = reinterpret_cast<const _Float16*>(&w);

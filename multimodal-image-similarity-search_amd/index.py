@@ -14,8 +14,8 @@ import numpy as np
 
 from . import _lib
 
-F32, F16 = _lib.MMISS_F32, _lib.MMISS_F16
-_DTYPES = {"f32": F32, "float32": F32, "f16": F16, "float16": F16, F32: F32, F16: F16}
+F32, F16, F8 = _lib.MMISS_F32, _lib.MMISS_F16, _lib.MMISS_F8
+_DTYPES = {"f32": F32, "float32": F32, "f16": F16, "float16": F16, "f8": F8, "fp8": F8, "e4m3": F8, F32: F32, F16: F16, F8: F8}
 
 
 def _is_torch(x) -> bool:

@@ -63,6 +63,13 @@ def normalize_rows(x: np.ndarray, dtype: str = "f32") -> np.ndarray:
     y = (x.astype(np.float64) / canon_norm(x)[..., None]).astype(np.float32)
     if dtype in ("f16", "float16", 1):
         return y.astype(np.float16)
+    if dtype in ("f8", "fp8", "e4m3", 2):
+        # MMISS_F8 (include/mmiss.h): e4m3 code of 128 * y (round to nearest even), stored value = decode(code) / 128 — returned as
+        # the float32 values the codes stand for (exactly representable), so that distances() / query() work on them unchanged
+        from oracle import fp8_oracle
+
+        codes = fp8_oracle.e4m3_encode(y * np.float32(128.0))
+        return (fp8_oracle.e4m3_decode(codes).astype(np.float32) * np.float32(1.0 / 128.0)).astype(np.float32)
     return y
 
 

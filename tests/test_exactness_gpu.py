@@ -82,7 +82,7 @@ def test_more_distinct_near_ties_than_the_slack(mods, dtype, Q):
     idx.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f8"])
 def test_thousands_of_exact_duplicates(mods, dtype):
     """5000 rows identical to the query spread over the index (a photo uploaded again and again): approximate scores tie
     EXACTLY, far more ties than any candidate page holds; the k smallest labels must win, for k = 10 and the UI's
@@ -107,7 +107,7 @@ def test_thousands_of_exact_duplicates(mods, dtype):
     idx.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f8"])
 def test_widen_pass_alone_reproduces_the_oracle(mods, dtype):
     """guard_force = 1 sends EVERY query through the widen pass (paging scan + re-rank rounds): it must return exactly
     what the ordinary path returns — the oracle's ids and distance bits — for every Q / k regime."""

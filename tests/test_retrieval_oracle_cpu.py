@@ -74,3 +74,31 @@ def test_merge_shards_equals_unsharded():
     ml, md, mc = ro.merge_shards(np.stack([p[1] for p in parts]), np.stack([p[0] for p in parts]), 10)
     np.testing.assert_array_equal(ml, full[0])
     np.testing.assert_array_equal(md, full[1])
+
+
+def test_fp8_storage_rounding_is_e4m3_of_128x():
+    """MMISS_F8 rows (include/mmiss.h): stored value = decode(e4m3(128 y)) / 128, round to nearest even. Hand-checked points,
+    the value grid, idempotence, and how far a stored unit row is from the unquantised one."""
+    from oracle import fp8_oracle
+    from oracle import retrieval_oracle as ro
+
+    # one row whose normalised form is known: (0.6, 0.8, 0, ...): 76.8 -> 80 (grid step 8 in [64, 128)), 102.4 -> 104
+    x = np.zeros((1, 128), np.float32)
+    x[0, 0], x[0, 1] = 3.0, 4.0
+    s = ro.normalize_rows(x, "f8")
+    assert s.dtype == np.float32 and s[0, 0] == 80.0 / 128.0 and s[0, 1] == 104.0 / 128.0 and not s[0, 2:].any()
+    rng = np.random.Generator(np.random.Philox(3))
+    c = rng.standard_normal((500, 512), dtype=np.float32)
+    s8, s32 = ro.normalize_rows(c, "f8"), ro.normalize_rows(c, "f32")
+    grid = set((fp8_oracle.e4m3_table()[:127] / 128.0).astype(np.float32).tolist())
+    assert set(np.abs(s8).ravel().tolist()) <= grid                      # every stored value is an e4m3 value / 128
+    again = (fp8_oracle.e4m3_decode(fp8_oracle.e4m3_encode(s8 * np.float32(128))) / np.float32(128)).astype(np.float32)
+    np.testing.assert_array_equal(again, s8)                             # idempotent
+    rel = np.abs(s8 - s32)[np.abs(s32) > 2.0 ** -6 / 128] / np.abs(s32)[np.abs(s32) > 2.0 ** -6 / 128]
+    assert rel.max() <= 2.0 ** -4 + 1e-6                                 # three mantissa bits in the normal range
+    nrm = np.linalg.norm(s8.astype(np.float64), axis=1)
+    cos = (s8.astype(np.float64) * s32).sum(1) / nrm
+    assert abs(nrm - 1).max() < 0.02 and (1 - cos).max() < 2e-3
+    # the oracle's query works on the stored values unchanged: self-query of a stored row returns it first
+    l, d, _ = ro.query(s8[7:8], s8, np.arange(500, dtype=np.int64), 3)
+    assert l[0, 0] == 7 and abs(d[0, 0] - (1 - float(nrm[7]))) < 1e-6   # distance to itself = 1 - |stored row| (q is normalised, the row is not)

@@ -87,6 +87,7 @@ Retrieval, 10M × 512 f16 on one GPU: Q = 1 {q1['ms_per_batch']:.3f} ms per quer
 8 TB/s spec); Q = 16 {r['Q16']['ms_per_batch']:.2f} ms; Q = 1024 **{qk['ms_per_batch']:.2f} ms per batch** (round 2: 10.66): threshold-filtered score GEMM on the staggered loop
 {qk['kernel_ms']['score_gemm_f16']:.2f} ms = {qk['score_gemm']['tflops'] / 1e3:.2f} PFLOP/s f16 = {100 * qk['score_gemm']['mfma_frac']:.1f} % of peak, sample pass {qk['kernel_ms']['score_gemm_f16_sample']:.2f}, select {qk['kernel_ms']['select_topk']:.2f}, merges {qk['kernel_ms']['merge_lists']:.2f}, rerank {qk['kernel_ms']['rerank']:.2f}.
 Exactness accounting over the run: {d['exactness']['queries']} + {r['exactness']['queries']} queries served, {d['exactness']['widened'] + r['exactness']['widened']} widened.
+The same rows stored as fp8 (`MMISS_F8`, `retrieval.f8_rows`): Q = 1 {r['f8_rows']['Q1']['ms_per_batch']:.3f} ms = {r['f8_rows']['Q1']['mvec_per_s'] / 1e3:.1f} G vec/s (scan {r['f8_rows']['Q1']['scan_kernel']['hbm_gbs'] / 1e3:.2f} TB/s over 5.1 GB), Q = 16 {r['f8_rows']['Q16']['ms_per_batch']:.2f} ms.
 
 ViT-L/14 geometry of the reference's checkpoint, bs 128: bf16 **{l['images_per_s_bs128'] / 1e3:.2f} k images/s** ({l['image_tflops']:.0f} TFLOP/s; round 2: 5.47 k), 1 − cos vs the fp32 oracle
 {l['max_1_minus_cos_vs_fp32_oracle']['image']:.1e} (image) / {l['max_1_minus_cos_vs_fp32_oracle']['text']:.1e} (text); fp8 vision tower **{f['images_per_s_bs128'] / 1e3:.2f} k images/s**, 1 − cos vs the oracle {f['max_1_minus_cos_vs_fp32_oracle']['image']:.1e}
