@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0           # spec; ~6.3 TB/s achievable (same guide)
 KERNEL_SYMBOL = {  # libmmiss kernel class -> symbol as rocprofv3 --kernel-trace prints it
     "gemm_bf16_f32": "gemm16_kernel<__bf16,BM,0>", "gemm_bf16_bias": "gemm16_kernel<__bf16,BM,1>",
     "gemm_bf16_bias_qgelu": "gemm16_kernel<__bf16,BM,2>", "gemm_bf16_bias_resid": "gemm16_kernel<__bf16,BM,3>",
-    "gemm_bf16_bias_resid16": "gemm16_kernel<__bf16,BM,9>", "gemm_bf16_bias_resid16_p160": "gemm160p_kernel<9,0>",
-    "gemm_bf16_patch_p160": "gemm160p_kernel<4,0>",
+    "gemm_bf16_bias_resid16": "gemm16_kernel<__bf16,BM,9>", "gemm_bf16_bias_resid16_p160": "gemm160p_kernel<9,0,K/64> (out-projection K = 768: <9,0,12>; FC2 K = 3072: <9,0,48>)",
+    "gemm_bf16_patch_p160": "gemm160p_kernel<4,0,0>",
     "gemm_bf16_lnfold_bias": "gemm256_kernel<__bf16,7> (>= 85 % tile fill) / gemm16_kernel<__bf16,BM,7>", "gemm_bf16_lnfold_qgelu": "gemm16_kernel<__bf16,BM,8>",
     "gemm_bf16_lnfold_bias_p256": "gemm256p_kernel<7,K/256,0,0>", "gemm_bf16_lnfold_qgelu_p256": "gemm256p_kernel<8,K/256,0,0>",
     "gemm_bf16_bias_p256": "gemm256p_kernel<1,0,0,0>", "gemm_bf16_bias_qgelu_p256": "gemm256p_kernel<2,0,0,0>",
@@ -498,6 +498,86 @@ def main():
                          "the partly empty last round of tiles and the store burst of every GEMM. NOT the headline value: kernel "
                          "durations overlap in this mode, so the roofline object is measured one batch at a time"}
 
+    # ---------------------------------------------------------------- configs[1] on ITS OWN index (N = 1 only)
+    # BASELINE configs[1] / SURVEY 8(d) config 2: every embedding is queried against the index OF those embeddings. The timed
+    # step above searches a random index, where the exactness guard proves ~every query from the first pass; the encoder's own
+    # embeddings (random weights: pairwise cosine ~0.99) sit closer together than the guard's error bound, so here EVERY query
+    # takes the widen (threshold) pass. Same pipelined step, same encoder, index = the embeddings of index_rows seeded images,
+    # queries = batches that are in the index (each must find itself first).
+    config1 = None
+    if rank == 0 and world == 1 and not args.no_text:
+        NS = args.index_rows
+        sidx = FlatIndex(D, "f16", device=local_rank, capacity=NS)
+        g1 = torch.Generator(device=dev).manual_seed(4321)
+        keep, tmp_e = [], torch.empty(B, D, device=dev)
+        t0 = time.perf_counter()
+        for b0 in range(0, NS, B):
+            n = min(B, NS - b0)
+            px1 = torch.randn(B, 3, 224, 224, device=dev, generator=g1)
+            enc.encode_image(px1, out=tmp_e)
+            sidx.add(tmp_e[:n], np.arange(b0, b0 + n, dtype=np.int64))
+            if len(keep) < NROT and n == B:
+                keep.append(px1)
+        torch.cuda.synchronize()
+        ingest_s = time.perf_counter() - t0
+        spend = [None]
+
+        def sstep(i):
+            enc.encode_image(keep[i % len(keep)], out=emb)
+            prev, spend[0] = spend[0], None
+            out = prev.result() if prev is not None else None
+            spend[0] = sidx.query_begin(emb, K_TOP)
+            return out
+
+        def sdrain():
+            prev, spend[0] = spend[0], None
+            return prev.result() if prev is not None else None
+
+        for i in range(3):
+            sstep(i)
+        sdrain()
+        fence()
+        gs0 = sidx.guard_stats()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sstep(i)
+        lab1, dst1, _c1 = sdrain()
+        fence()
+        sdt = (time.perf_counter() - t0) / args.steps
+        gs1 = sidx.guard_stats()
+        last_b = (args.steps - 1) % len(keep)
+        self_first = bool((lab1[:, 0].cpu() == torch.arange(last_b * B, (last_b + 1) * B)).all())
+
+        def q_ms(reps=10):
+            sidx.query(emb, K_TOP)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                sidx.query(emb, K_TOP)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / reps * 1e3
+
+        q_full = q_ms()
+        _lib.set_option("exact_guard", 0)
+        try:
+            q_first = q_ms()
+        finally:
+            _lib.set_option("exact_guard", 1)
+        config1 = {"index": f"{NS} x {D} f16 = the embeddings of {NS} seeded N(0,1) images under this encoder "
+                            f"(ingested in {ingest_s:.2f} s incl. image generation)",
+                   "images_per_s": round(B / sdt, 1), "ms_per_step": round(sdt * 1e3, 3),
+                   "vs_headline_step": round(sdt * 1e3 / ms_per_step, 3),
+                   "exactness_per_step": {k_: round((gs1[k_] - gs0[k_]) / args.steps, 2) for k_ in
+                                          ("queries", "widened", "rounds", "pages", "exhaustive", "swept_rows")},
+                   "query_stage_ms": {"first_pass_plus_widen": round(q_full, 4), "first_pass_only_guard_off": round(q_first, 4),
+                                      "ratio": round(q_full / q_first, 3)},
+                   "every_query_finds_itself_first": self_first,
+                   "max_self_distance": float(dst1[:, 0].max().item()),
+                   "note": "NOT the headline value (the contract's step searches the configs[1] index of random rows); the full "
+                           "ingest-then-query-back flow under the oracle is tests/test_headline_gpu.py::test_config1_100k_..."}
+        sidx.close()
+        del keep
+
     # ---------------------------------------------------------------- the same step with the fp8 GEMMs (N = 1 only, opt-in path)
     b32_fp8 = None
     if rank == 0 and world == 1 and not args.no_text:
@@ -644,7 +724,7 @@ def main():
             "exactness": dict(index.guard_stats(), note="queries served by the step's index / of them not provable from the "
                               "first pass and widened (mmiss_index_guard_stats)"),
             "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest,
-            "two_batches_in_flight": lanes, "fp8_gemms": b32_fp8, "l14": l14,
+            "config1_self_index": config1, "two_batches_in_flight": lanes, "fp8_gemms": b32_fp8, "l14": l14,
             "cpu_baseline": cpu if world == 1 else {"see": "the N = 1 line of the same commit: the CPU baseline is timed on rank 0 "
                                                            "at N = 1 only (it needs the host cores the other ranks' launch threads use)"},
             "distributed": distributed,
@@ -666,8 +746,10 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
         n = min(chunk, per - r0)
         idx.add(torch.randn(n, D, device=dev, generator=gen), np.arange(rank * per + r0, rank * per + r0 + n, dtype=np.int64))
     res = {"rows": N, "rows_per_gpu": per, "dim": D, "dtype": "f16", "k": K_TOP}
+    q_all = torch.randn(1024, D, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    first = {}   # query 0's (labels, distance bits) from every leg: scan (Q = 1, 16) and score GEMM (Q = 1024) must agree
     for Q, iters in ((1, 20), (16, 10), (1024, 3)):
-        q = torch.randn(Q, D, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+        q = q_all[:Q].contiguous()
 
         def run():
             lab, dst, _ = idx.query(q, K_TOP)
@@ -676,7 +758,8 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
                 return merge_topk(dst_all, lab_all)
             return lab, dst
 
-        run()
+        r0_ = run()
+        first[Q] = (r0_[0][0].cpu().numpy().copy(), r0_[1][0].cpu().numpy().view(np.uint32).copy())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -713,7 +796,57 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
         res[f"Q{Q}"] = entry
     res["headline_mvec_per_s"] = res["Q1"]["mvec_per_s"]
     res["exactness"] = idx.guard_stats()
+    same = all(np.array_equal(first[1][0], first[Q][0]) and np.array_equal(first[1][1], first[Q][1]) for Q in (16, 1024))
+    res["check"] = {"first_query_ids_and_distance_bits_identical_across_Q1_Q16_Q1024": bool(same),
+                    "note": "outside the timed loops: the three legs share their first query; Q = 1 / 16 take the streaming scan, "
+                            "Q = 1024 the score GEMM + threshold-filtered selection; the same rows at 10M x 512 and 6.25M x 768 "
+                            "against the C oracle: tests/test_headline_gpu.py::test_full_size_index_against_the_oracle"}
     idx.close()
+    # the widen pass at full size: a CLUSTERED 10M-row index (one common direction + 10 % noise: pairwise
+    # cosine 0.99, like the embeddings of one encoder) queried with 1024 of its own rows — the exactness guard cannot prove
+    # any query from the first pass, every one takes the threshold pass
+    if world == 1 and N >= 1_000_000:
+        idc = FlatIndex(D, "f16", device=local_rank, capacity=N)
+        genc = torch.Generator(device=dev).manual_seed(77)
+        centre = torch.randn(1, D, device=dev, generator=genc)
+        centre = centre / centre.norm()
+        qc = None
+        for r0 in range(0, N, chunk):
+            n = min(chunk, N - r0)
+            rows_c = centre + 0.1 * torch.randn(n, D, device=dev, generator=genc) / D ** 0.5
+            if qc is None:
+                qc = rows_c[:1024].clone()
+            idc.add(rows_c, np.arange(r0, r0 + n, dtype=np.int64))
+        del rows_c
+        lab_c, dst_c, _ = idc.query(qc, K_TOP)
+        torch.cuda.synchronize()
+        g0 = idc.guard_stats()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            idc.query(qc, K_TOP)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t0) / 3
+        g1 = idc.guard_stats()
+        _lib.set_option("exact_guard", 0)
+        try:
+            idc.query(qc, K_TOP)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                idc.query(qc, K_TOP)
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t0) / 3
+        finally:
+            _lib.set_option("exact_guard", 1)
+        res["clustered_Q1024"] = {
+            "rows": N, "ms_per_batch": round(dtc * 1e3, 3), "first_pass_only_ms": round(dtf * 1e3, 3),
+            "ratio_to_first_pass": round(dtc / dtf, 3),
+            "per_batch": {k_: (g1[k_] - g0[k_]) // 3 for k_ in ("queries", "widened", "rounds", "pages", "exhaustive", "swept_rows")},
+            "self_match_first": bool((lab_c[:, 0].cpu() == torch.arange(1024)).all()),
+            "note": "rows = unit(centre + 0.1 noise): every query fails the guard's proof and is widened by ONE threshold pass "
+                    "(score GEMM over the whole index again, rows with approx >= c_k - eps appended, exact re-rank); "
+                    "first_pass_only_ms = the same batch with the guard switched off (results unproven)"}
+        idc.close()
     # BASELINE configs[4] index shape: one of the 8 row shards of the 50M x 768 f16 index (6.25M rows, 9.6 GB), N = 1 only
     if world == 1 and N >= 10_000_000:
         N8, D8 = 6_250_000, 768
@@ -721,9 +854,12 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
         for r0 in range(0, N8, 1_250_000):
             idx8.add(torch.randn(1_250_000, D8, device=dev, generator=gen), np.arange(r0, r0 + 1_250_000, dtype=np.int64))
         shard = {"rows": N8, "dim": D8, "dtype": "f16", "note": "one GPU's shard of BASELINE configs[4] (50M x 768 over 8 GPUs)"}
+        q8_all = torch.randn(128, D8, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+        first8 = {}
         for Q, iters in ((1, 10), (128, 5)):
-            q = torch.randn(Q, D8, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
-            idx8.query(q, K_TOP)
+            q = q8_all[:Q].contiguous()
+            l8_, d8_, _ = idx8.query(q, K_TOP)
+            first8[Q] = (l8_[0].cpu().numpy().copy(), d8_[0].cpu().numpy().view(np.uint32).copy())
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(iters):
@@ -732,6 +868,8 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
             dt = (time.perf_counter() - t0) / iters
             shard[f"Q{Q}"] = {"ms_per_batch": round(dt * 1e3, 3), "mvec_per_s": round(N8 / dt / 1e6, 1),
                               "hbm_gbs_equiv": round(N8 * D8 * 2 / dt / 1e9, 1)}
+        shard["first_query_ids_and_distance_bits_identical_across_Q1_Q128"] = bool(
+            np.array_equal(first8[1][0], first8[128][0]) and np.array_equal(first8[1][1], first8[128][1]))
         idx8.close()
         res["shard_50Mx768"] = shard
         # the same 10M x 512 rows stored as fp8 (MMISS_F8: e4m3 codes of 128 x, half the bytes of f16 per row), N = 1 only,
@@ -811,18 +949,28 @@ def cpu_baseline(W, D, index_rows, k):
     enc = {}
     emb = None
 
-    def rate(bs, n_img, threads):
+    passes = {}
+
+    def rate(name, bs, n_img, threads, n_pass):
+        """best of n_pass passes over the same n_img images, every pass listed (one 32-image pass swung 72 <-> 149 images/s
+        between boxes of the same CPU model in round 3: a single pass measures the box's other tenants as much as the CPU)"""
         torch.set_num_threads(threads)
         ct.embed_images(px[:bs], Wt, co.VIT_B32)  # warm-up
-        t0 = time.perf_counter()
-        out = [ct.embed_images(px[i:i + bs], Wt, co.VIT_B32) for i in range(0, n_img, bs)]
-        dt = time.perf_counter() - t0
-        return n_img / dt, torch.cat(out).numpy()
+        best, out = 0.0, None
+        passes[name] = []
+        for _ in range(n_pass):
+            t0 = time.perf_counter()
+            out = [ct.embed_images(px[i:i + bs], Wt, co.VIT_B32) for i in range(0, n_img, bs)]
+            r = n_img / (time.perf_counter() - t0)
+            passes[name].append(round(r, 2))
+            best = max(best, r)
+        enc[name] = best
+        return torch.cat(out).numpy()
 
-    enc["bs1_1thread"], _ = rate(1, 4, 1)
-    enc[f"bs1_{share}threads"], _ = rate(1, 16, share)
-    enc["bs32_1thread"], _ = rate(32, 32, 1)
-    enc[f"bs32_{share}threads"], emb = rate(32, 32, share)
+    rate("bs1_1thread", 1, 3, 1, 2)
+    rate(f"bs1_{share}threads", 1, 8, share, 3)
+    rate("bs32_1thread", 32, 32, 1, 1)
+    emb = rate(f"bs32_{share}threads", 32, 32, share, 3)
     torch.set_num_threads(old_threads)
     # retrieval on the CPU: exact brute force (what chromadb does below 100 rows and approximates above), unit rows in fp32,
     # one BLAS GEMM + top-k for the 32 queries on all threads of the share
@@ -831,10 +979,13 @@ def cpu_baseline(W, D, index_rows, k):
     qt = torch.from_numpy(emb)
     torch.set_num_threads(share)
     torch.topk(qt @ corpus.T, k, dim=1)  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(5):
-        d_, i_ = torch.topk(1.0 - qt @ corpus.T, k, dim=1, largest=False)
-    t_q = (time.perf_counter() - t0) / 5 / qt.shape[0]
+    t_q = None
+    for _ in range(3):   # best of 3 passes of 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            d_, i_ = torch.topk(1.0 - qt @ corpus.T, k, dim=1, largest=False)
+        t_ = (time.perf_counter() - t0) / 3 / qt.shape[0]
+        t_q = t_ if t_q is None or t_ < t_q else t_q
     torch.set_num_threads(old_threads)
     best = enc[f"bs32_{share}threads"]
     cpu_model = platform.processor() or ""
@@ -844,11 +995,12 @@ def cpu_baseline(W, D, index_rows, k):
     except Exception:
         pass
     return {"value": round(1.0 / (1.0 / best + t_q), 2), "unit": "images/s", "cores": int(share), "kind": "port",
-            "sample": f"PyTorch-CPU fp32 restatement of the reference's path: 32 images at bs=32 on {share} threads "
+            "sample": f"PyTorch-CPU fp32 restatement of the reference's path (best of 3 passes, all listed): 32 images at bs=32 on {share} threads "
                       f"({1e3 / best:.1f} ms/img) + exact brute-force cosine top-{k} of those 32 embeddings vs {index_rows}x{D} "
                       f"fp32 unit rows, one GEMM + topk on {share} threads ({t_q * 1e3:.2f} ms/query); host: {cpu_model}, "
                       f"{os.cpu_count()} logical CPUs",
             "encode_only_images_per_s": {k_: round(v, 2) for k_, v in enc.items()},
+            "encode_only_images_per_s_every_pass": passes,
             "reference_regime": "bs1 (backend/app/utils.py:76-77 encodes one image per request)",
             "query_ms": round(t_q * 1e3, 3)}
 

@@ -231,19 +231,28 @@ int mmiss_index_query_begin(mmiss_index* idx, const float* queries, int32_t Q, i
                             int64_t* out_labels, float* out_dist, int32_t* out_count);
 int mmiss_index_query_end(mmiss_index* idx);
 /*
+ * Give up a query opened with _begin (the caller lost interest: an exception in the serving loop between the two halves):
+ * waits for the queued first pass — it still writes the output buffers, which must stay valid until this returns — and
+ * re-opens the handle for other calls. No results are delivered. Without an open query: MMISS_OK, nothing happens.
+ */
+int mmiss_index_query_abort(mmiss_index* idx);
+/*
  * Exactness accounting since the index was created ("top-10 recall = 1.0" is proven per query, not assumed): the first
- * pass ranks by approximate matrix-core scores and keeps k' > k rows; a query whose k-th exact score does not clear the
- * best score that pass may have left out by more than the arithmetic's error bound is widened (more candidates, exact
- * re-rank) until it does. out[0] = queries served, out[1] = queries widened, out[2] = widen rounds, out[3] = extra
- * scan pages read. No reference analogue (chromadb's HNSW is approximate above 100 rows).
+ * pass ranks by approximate matrix-core scores and keeps k' > k rows; a query whose k-th exact score c_k does not clear the
+ * best score that pass may have left out by more than the arithmetic's error bound eps_q is widened: ONE threshold pass
+ * over the index for all such queries of the call collects every row whose approximate score reaches c_k - eps_q (every
+ * row that can still belong to the top-k), and the exact re-rank of those rows is the answer.
+ * out[0] = queries served, out[1] = queries widened, out[2] = widen passes run (one per call that had to widen),
+ * out[3] = extra passes over the index those cost (1 per widen pass on the score GEMM, one per 64 widened queries on the
+ * streaming scan). No reference analogue (chromadb's HNSW is approximate above 100 rows).
  */
 int mmiss_index_guard_stats(mmiss_index* idx, int64_t out[4]);
 /*
- * The same four counters and, in out[4], the queries that were still unproven after three widen rounds and went through
- * the exhaustive canonical pass instead (the canonical distance of every row, the k best by (distance, label)): a plateau of
- * more rows within the rounding bound of the k-th score than paging walks in reasonable time — e.g. > 10^5 copies of one
- * placeholder image. Exact for any data; costs one pass over the index and one host selection per such query.
- * out[5..7] are reserved (0).
+ * The same four counters and: out[4] = the queries whose threshold pass collected more than 8192 rows and went through the
+ * exhaustive canonical pass instead (the canonical distance of every row, the k best by (distance, label)) — a plateau of
+ * rows within the rounding bound of the k-th score, e.g. > 10^4 copies of one placeholder image; exact for any data, one
+ * pass over the index and one host selection per such query. out[5] = rows the threshold passes collected and re-ranked.
+ * out[6..7] are reserved (0).
  */
 int mmiss_index_guard_stats_ex(mmiss_index* idx, int64_t out[8]);
 

@@ -85,8 +85,10 @@ int mmiss_dbg_gemm8_time(int device, int epi, int bm, const void* A8, const void
                          const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K, int32_t iters,
                          float* ms_per_launch);
 
-/* bit 0: the library was built with MMISS_EXPERIMENTS (ring GEMM variants 1000 + BM, BM x 256 tiles 2000 + BM, LayerNorm
- * mode 1); the product build returns 0 and rejects those with MMISS_ERR_UNSUPPORTED */
+/* bit 0: the library was built with MMISS_EXPERIMENTS (A/B variants kept for timing; the product build rejects them with
+ * MMISS_ERR_UNSUPPORTED). bit 1: one of its translation units was built with a timing-experiment macro of tools/*_ab.sh
+ * (P256_NO_LATE_WAIT, P256_SPLIT_STAGE, MMISS_SCAN_NT) — NOT a product build: mmiss_amd._lib.load() refuses it unless
+ * MMISS_ALLOW_AB_BUILD=1, so that no test or bench run is attributed to HEAD by accident. The product build returns 0. */
 int mmiss_dbg_build_flags(void);
 
 /* process-wide integer tuning knob (A/B experiments from tools/): e.g. "scan_group" = 8 | 16 */

@@ -84,6 +84,7 @@ SIGNATURES = {
     "mmiss_index_query": (_I, [_P, _P, _I32, _I32, _P, _P, _P]),
     "mmiss_index_query_begin": (_I, [_P, _P, _I32, _I32, _P, _P, _P]),
     "mmiss_index_query_end": (_I, [_P]),
+    "mmiss_index_query_abort": (_I, [_P]),
     "mmiss_index_guard_stats": (_I, [_P, C.POINTER(_I64)]),
     "mmiss_index_guard_stats_ex": (_I, [_P, C.POINTER(_I64)]),
     "mmiss_index_save": (_I, [_P, C.c_char_p]),
@@ -137,6 +138,11 @@ def load() -> C.CDLL:
             fn.argtypes = args
         if lib.mmiss_abi_version() != 1:
             raise ImportError("libmmiss.so ABI version mismatch")
+        if (lib.mmiss_dbg_build_flags() & 2) and os.environ.get("MMISS_ALLOW_AB_BUILD") != "1":
+            raise ImportError(
+                f"{LIB_PATH} was built with a timing-experiment macro (tools/*_ab.sh: P256_NO_LATE_WAIT, P256_SPLIT_STAGE, "
+                "MMISS_SCAN_NT) and is not a product build; rebuild it (`make -C .../csrc clean all`) or set "
+                "MMISS_ALLOW_AB_BUILD=1 for the A/B run itself")
         _lib = lib
         # experiment knobs from the environment: MMISS_OPTIONS="gemm_wide=1,scan_rounds=2" (see mmiss_dbg_set_option)
         for kv in filter(None, os.environ.get("MMISS_OPTIONS", "").split(",")):

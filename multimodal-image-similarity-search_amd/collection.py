@@ -136,7 +136,11 @@ class FlatCollection:
         jl, jv = self._journal_paths(self._index_gen)
         if not os.path.exists(jl):
             return
-        vec = np.memmap(jv, dtype=np.float32, mode="r") if os.path.exists(jv) and os.path.getsize(jv) else None
+        # The vector file may end in a torn write (a crash inside f.write of the vectors — the large write, so the likelier one
+        # to tear): its size need not be a multiple of 4. Map only the whole floats; the tail is cut off below.
+        vec_bytes = os.path.getsize(jv) if os.path.exists(jv) else 0
+        vec = np.memmap(jv, dtype=np.float32, mode="r", shape=(vec_bytes // 4,)) if vec_bytes >= 4 else None
+        vec_end = 0           # byte offset just behind the last committed record's vectors
         autosave, self._autosave = self._autosave, False   # replay must not journal again
         good_end = 0          # byte offset just behind the last committed record
         torn = needs_newline = False
@@ -156,7 +160,11 @@ class FlatCollection:
                         if vec is None or (o + n * d) > vec.shape[0]:
                             torn = True                      # the commit line survived, its vectors did not: not committed
                             break
+                        if rec["offset"] % 4:
+                            torn = True                      # (written behind a torn tail by a build without the cut below)
+                            break
                         emb = np.array(vec[o:o + n * d]).reshape(n, d)
+                        vec_end = max(vec_end, (o + n * d) * 4)
                     if rec["op"] == "add":
                         self.add(rec["ids"], emb, rec.get("metadatas"), rec.get("documents"))
                     elif rec["op"] == "update":
@@ -176,6 +184,14 @@ class FlatCollection:
                 if needs_newline:
                     f.seek(good_end)
                     f.write(b"\n")
+                f.flush()
+                os.fsync(f.fileno())
+        # ... and the vector file ending behind the last committed record's vectors: the next append records f.tell() as its
+        # offset, which must be 4-aligned and must not sit behind bytes no record owns.
+        if vec_bytes > vec_end:
+            del vec
+            with open(jv, "r+b") as f:
+                f.truncate(vec_end)
                 f.flush()
                 os.fsync(f.fileno())
 

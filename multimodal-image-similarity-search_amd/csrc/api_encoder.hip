@@ -1145,12 +1145,16 @@ extern "C" int mmiss_dbg_encoder_set_fuse_ln(mmiss_encoder* enc, int on) {
     return MMISS_OK;
 }
 
+int mmiss_index_build_flags(void);   // api_index.hip: the same question for that translation unit
 extern "C" int mmiss_dbg_build_flags(void) {
+    int f = mmiss_index_build_flags();
 #ifdef MMISS_EXPERIMENTS
-    return 1;
-#else
-    return 0;
+    f |= 1;
 #endif
+#if defined(P256_NO_LATE_WAIT) || defined(P256_SPLIT_STAGE) || defined(MMISS_SCAN_NT)
+    f |= 2;   // built with a timing-experiment macro (tools/*_ab.sh): NOT a product build
+#endif
+    return f;
 }
 
 extern "C" int mmiss_dbg_encoder_record_taps(mmiss_encoder* enc, int on) {

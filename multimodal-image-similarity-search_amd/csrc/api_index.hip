@@ -23,9 +23,9 @@ struct mmiss_index {
     // scratch
     DevBuf stage, qn, qs, qstage, lists_s, lists_r, lists2_s, lists2_r, cand, cur_s, cur_r, out_c, map, gmax;
     // exactness guard + widen pass (see "exactness contract" above mmiss_index_query)
-    DevBuf flags, nflag_d, qmap, qmap64, qs2, cand2, cur2_s, cur2_r;
+    DevBuf qmap, qmap64, qs2, cand2;
+    DevBuf eps_q, thr, thr2, swp_cnt, swp_list;   // per-query error bound, sweep thresholds (all / flagged queries), appended rows
     DevBuf seed_s, seed_r, fcnt, fbuf_s, fbuf_g;  // threshold-filtered selection (Q > 128)
-    int32_t* nflag_h = nullptr;  // pinned
     // Pinned, device-visible host block a query's LAST kernel (the rerank) writes straight into: the guard's per-query flags
     // always, and labels / distances / counts when the caller's outputs are host buffers. The call then ends with ONE stream
     // synchronisation and no copy-engine operation (round 3: four small device-to-host copies used to sit there, ~25 us).
@@ -40,7 +40,7 @@ struct mmiss_index {
         pin_bytes = cap;
         return MMISS_OK;
     }
-    int64_t stat_queries = 0, stat_flagged = 0, stat_rounds = 0, stat_pages = 0, stat_exhaustive = 0;
+    int64_t stat_queries = 0, stat_flagged = 0, stat_rounds = 0, stat_pages = 0, stat_exhaustive = 0, stat_swept_rows = 0;
     // a query between mmiss_index_query_begin and mmiss_index_query_end: its first pass is queued, `done_ev` marks its end
     struct Pending {
         bool active = false, out_dev = false, guard = false;
@@ -55,6 +55,14 @@ struct mmiss_index {
 // every other entry point refuses to run between query_begin and query_end (the scratch buffers belong to that query)
 #define MM_NO_PENDING(ix, who) \
     do { if ((ix)->pend.active) MM_FAIL(MMISS_ERR_STATE, "%s: a query begun with mmiss_index_query_begin is still open", who); } while (0)
+
+int mmiss_index_build_flags(void) {
+#if defined(P256_NO_LATE_WAIT) || defined(P256_SPLIT_STAGE) || defined(MMISS_SCAN_NT)
+    return 2;
+#else
+    return 0;
+#endif
+}
 
 namespace {
 
@@ -111,6 +119,14 @@ template <typename T, int NQT, int CAP, int GS = 8>
 int launch_scan_t(hipStream_t st, const ScanArgs& a, int slabs, int qtiles, int lds) {
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&scan_topk_kernel<T, NQT, CAP, GS>), lds));
     hipLaunchKernelGGL((scan_topk_kernel<T, NQT, CAP, GS>), dim3(slabs, qtiles), dim3(256), lds, st, a);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+template <typename T, int NQT>
+int launch_scan_thr_t(hipStream_t st, const ScanArgs& a, int slabs, int qtiles, int lds) {
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&scan_topk_kernel<T, NQT, 32, 8, true>), lds));
+    hipLaunchKernelGGL((scan_topk_kernel<T, NQT, 32, 8, true>), dim3(slabs, qtiles), dim3(256), lds, st, a);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }
@@ -210,17 +226,15 @@ extern "C" int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device
         delete ix;
         MM_FAIL(MMISS_ERR_HIP, "hipStreamCreate failed");
     }
-    if (hipHostMalloc(reinterpret_cast<void**>(&ix->nflag_h), 64, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&ix->done_ev, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&ix->done_ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(ix->own_stream);
-        if (ix->nflag_h) (void)hipHostFree(ix->nflag_h);
         delete ix;
-        MM_FAIL(MMISS_ERR_HIP, "hipHostMalloc / hipEventCreate failed");
+        MM_FAIL(MMISS_ERR_HIP, "hipEventCreate failed");
     }
     if (capacity_hint > 0) {
         int rc = index_reserve(ix, capacity_hint, ix->own_stream);
         if (rc != MMISS_OK) {
-            (void)hipStreamDestroy(ix->own_stream); (void)hipHostFree(ix->nflag_h); (void)hipEventDestroy(ix->done_ev);
+            (void)hipStreamDestroy(ix->own_stream); (void)hipEventDestroy(ix->done_ev);
             delete ix;
             return rc;
         }
@@ -234,7 +248,6 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
-    if (ix->nflag_h) (void)hipHostFree(ix->nflag_h);
     if (ix->pin) (void)hipHostFree(ix->pin);
     if (ix->done_ev) (void)hipEventDestroy(ix->done_ev);
     delete ix;
@@ -438,30 +451,38 @@ extern "C" int mmiss_index_labels(mmiss_index* ix, int64_t* out, int64_t cap) {
 }
 
 // ================================================================================================ exactness contract
-// Stage 1 orders rows by APPROXIMATE scores (matrix cores, f32 accumulation, f16 query operand for f16 rows) and keeps
+// Stage 1 orders rows by APPROXIMATE scores (matrix cores, f32 accumulation, f16 query operand for f16 / fp8 rows) and keeps
 // k' > k of them; stage 2 re-scores the survivors canonically (fp64, fixed order) and sorts. That is exact by construction
 // only if no row left out by stage 1 can belong to the true top-k, so stage 2 PROVES it per query:
-//   every left-out row r has approx(r) <= tau (tau = the k'-th approximate score / group maximum, the paging cursor),
-//   |approx(r) - canonical(r)| <= eps for every row (bound below), so canonical(r) <= tau + eps;
-//   if the k-th canonical score c_k of the candidates satisfies c_k - tau > eps, nothing left out reaches c_k.
-// A query that fails the test is WIDENED: it is re-run through the paging scan (rows strictly after the cursor, 32 per
-// page), rounds of geometrically more pages, each round re-ranking {best rows so far} + {new pages}, until the test
-// passes or the cursor runs off the index. Exact for any data (near-duplicates, thousands of ties); on random data the
-// test fails for about one query in 10^4 (k = 10: the gap between the 10th and the 16th best score vs eps ~ 6e-4).
+//   every left-out row r has approx(r) <= tau (tau = the k'-th approximate score / group maximum),
+//   |approx(r) - canonical(r)| <= eps_q for every row (bound below), so canonical(r) <= tau + eps_q;
+//   if the k-th canonical score c_k of the candidates satisfies c_k - tau > eps_q, nothing left out reaches c_k.
+// A query that fails the test is WIDENED by ONE threshold pass (round 4; it used to page through the index 32 rows per
+// full scan): c_k is a lower bound of the true k-th canonical score, so every row of the true top-k has
+// approx >= c_k - eps_q =: thr_q. One more pass over the index — the score GEMM for many flagged queries of an f16 index, the
+// streaming scan otherwise — appends EVERY row with approx >= thr_q to the query's list; the canonical re-rank of that list
+// is the exact answer (rows not on it have canonical <= approx + eps_q < c_k <= true c_k: strictly behind rank k, whatever
+// the tie-break). A list that overflows its capacity (a plateau: more than SWEEP_CAP rows within eps of the k-th score,
+// e.g. 10^5 uploads of one placeholder image) sends the query to the exhaustive canonical pass. Exact for any data; on
+// random data the test fails for about one query in 10^4, on the encoder's own embeddings (pairwise cosine 0.99) for all.
 namespace {
 
-double guard_eps(const mmiss_index* ix) {
-    // f32 accumulation of D exact products in hardware order: <= 4 D 2^-24 sum|q_d c_d| (factor 4: margin for the MFMA's
-    // internal alignment/truncation) <= 4 D 2^-24 |q||c|.  f16 rows: the scan's query operand is f16(qn), |f16(x) - x| <=
-    // 2^-11 |x| (+ 2^-25 in the subnormal range), so the operand rounding moves a score by <= 2^-11 |q||c| + D 2^-25.
-    // |q||c| <= (1 + 2^-10)^2; the float rounding of the canonical distance (<= 2) is 2^-23 at most.
+constexpr int SWEEP_CAP = 8192;   // rows a widened query may collect (= the re-rank kernel's sort capacity)
+
+// the guard's bound, split into what is the same for every query and the factor of the query operand's ACTUAL rounding error
+// |qs - qn|_2 (prep_queries_kernel computes eps_q = fixed + cnorm * |qs - qn|_2 per query):
+//   f32 accumulation of D exact products in hardware order: <= 4 D 2^-24 sum|q_d c_d| (factor 4: margin for the MFMA's
+//   internal alignment / truncation) <= 4 D 2^-24 |q||c|, |q||c| <= (1 + 2^-10)^2 (f16 / f32 rows);
+//   f16 / fp8 rows: the scan's query operand is f16(qn); <f16(qn) - qn, c> <= |f16(qn) - qn|_2 |c|_2 (+ D 2^-25: products
+//   of subnormal-range operands); a stored fp8 row's norm is within 1.07 of 1 (three mantissa bits per component);
+//   the float rounding of the canonical distance (<= 2) is 2^-23 at most.
+void guard_terms(const mmiss_index* ix, double* fixed, double* cnorm) {
     const double D = ix->dim;
-    double e = 4.0 * D * ldexp(1.0, -24);
-    if (ix->dtype == MMISS_F16) e += ldexp(1.0, -11) + D * ldexp(1.0, -25);
-    // fp8 rows: the scan's row operand is exact (e4m3 codes widen exactly to f16) and the query operand is rounded to f16 as
-    // above; a stored row's norm is within (1 + 2^-4) of 1 (three mantissa bits per component)
-    if (ix->dtype == MMISS_F8) e += ldexp(1.0, -11) * 1.07 + D * ldexp(1.0, -25);
-    return e * 1.003 + ldexp(1.0, -21);
+    const double cn = ix->dtype == MMISS_F8 ? 1.07 : 1.0 + ldexp(1.0, -9);
+    double e = 4.0 * D * ldexp(1.0, -24) * cn * (1.0 + ldexp(1.0, -9));
+    if (ix->dtype != MMISS_F32) e += D * ldexp(1.0, -25);
+    *fixed = e * 1.003 + ldexp(1.0, -21);
+    *cnorm = ix->dtype == MMISS_F32 ? 0.0 : cn * 1.003;
 }
 
 int launch_rerank(mmiss_index* ix, hipStream_t st, const RerankArgs& r, int blocks) {
@@ -470,21 +491,17 @@ int launch_rerank(mmiss_index* ix, hipStream_t st, const RerankArgs& r, int bloc
     const int lds = npow * 8 + 16;
     MM_PROF("rerank", st, 2.0 * blocks * r.ncand * r.D, (double)blocks * r.ncand * r.D * ix->elt);
     const int threads = r.ncand >= 16 ? 1024 : 256;  // one wave per candidate row: more waves hide the gather latency
-    if (ix->dtype == MMISS_F16)
+    if (ix->dtype == MMISS_F16) {
+        if (lds > 32768) MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&rerank_kernel<_Float16>), lds));
         hipLaunchKernelGGL(rerank_kernel<_Float16>, dim3(blocks), dim3(threads), lds, st, r);
-    else if (ix->dtype == MMISS_F8)
+    } else if (ix->dtype == MMISS_F8) {
+        if (lds > 32768) MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&rerank_kernel<F8>), lds));
         hipLaunchKernelGGL(rerank_kernel<F8>, dim3(blocks), dim3(threads), lds, st, r);
-    else
+    } else {
+        if (lds > 32768) MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&rerank_kernel<float>), lds));
         hipLaunchKernelGGL(rerank_kernel<float>, dim3(blocks), dim3(threads), lds, st, r);
+    }
     MM_HIP(hipGetLastError());
-    return MMISS_OK;
-}
-
-// number of flagged queries of the rerank just launched (host value; synchronises the stream)
-int read_nflag(mmiss_index* ix, hipStream_t st, int* n) {
-    MM_HIP(hipMemcpyAsync(ix->nflag_h, ix->nflag_d.p, 4, hipMemcpyDeviceToHost, st));
-    MM_HIP(hipStreamSynchronize(st));
-    *n = *ix->nflag_h;
     return MMISS_OK;
 }
 
@@ -545,29 +562,55 @@ int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_
     return MMISS_OK;
 }
 
-// the widen pass for the queries listed in `which` (original indices); results overwrite their rows of d_lab / d_dist / d_cnt
-int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& which, int k, int64_t* d_lab, float* d_dist,
+// consecutive index tiles per workgroup of the strip score GEMM (Mq queries padded to 256, ncol column tiles of 256 rows):
+// long enough to amortise the pipeline fill, short enough to leave >= 8 workgroups per CU for balance; among the strip
+// lengths down to half that, the one whose rounds x length (+ a quarter tile of pipeline fill per workgroup and round) is
+// smallest (10M rows x 1024 queries: strip 32 gave 4884 workgroups = 19.08 rounds of 256 -> 5 % of the launch spent with 18
+// workgroups on the chip).
+int strip_length(int Mq, int64_t nbn, int64_t ncol) {
+    const int64_t tiles = nbn * (Mq / 256);
+    int strip = (int)std::min<int64_t>(32, std::max<int64_t>(1, tiles / 2048));
+    if (strip >= 8 && mmiss_option("score_strip_fit", 1) != 0) {
+        double best = 1e300;
+        int best_s = strip;
+        for (int sl = strip; sl >= strip / 2; --sl) {
+            const int64_t wgs = (Mq / 256) * ((ncol + sl - 1) / sl);
+            const int64_t rounds = (wgs + 255) / 256;
+            const double cost = (double)rounds * (sl + 0.25);
+            if (cost < best - 1e-9) { best = cost; best_s = sl; }
+        }
+        strip = best_s;
+    }
+    const int forced = mmiss_option("score_strip", 0);
+    if (forced > 0) strip = forced;
+    return strip;
+}
+
+// The widen pass for the queries listed in `which` (original indices): ONE threshold pass over the index for all of them
+// (thr_q = c_k - eps_q, left in ix->thr by the first pass's re-rank), the canonical re-rank of the rows it collected, and the
+// exhaustive pass for the lists that overflowed. Results overwrite the queries' rows of d_lab / d_dist / d_cnt. Returns with
+// the stream drained.
+int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& which, int k, int64_t* d_lab, float* d_dist,
                   int32_t* d_cnt) {
-    const int Qf = (int)which.size(), D = ix->dim, KP = 32, CAPF = 4096;
+    const int Qf = (int)which.size(), D = ix->dim;
     const int64_t N = ix->count;
-    const int kk = (int)std::min<int64_t>(k, N);
-    const int kkpad = (int)round_up(std::max(kk, 1), KP);
-    const int Qfp = (int)round_up(Qf, 64);
+    if (Qf == 0 || N <= 0) return MMISS_OK;
+    // the score GEMM for an f16 index once the flagged queries fill a quarter of a 256-query tile (it costs about what 1.2
+    // streaming scans cost, and a scan serves 64 queries), the scan otherwise
+    const bool gemm = ix->dtype == MMISS_F16 && (D % 128) == 0 && D >= 256 && Qf > mmiss_option("sweep_gemm_min_q", 64) &&
+                      mmiss_option("score_strip_v3", 1) != 0;
+    const int Qfp = (int)round_up(Qf, 256);
     std::vector<int64_t> map64(which.begin(), which.end());
     MM_TRY(ix->qmap.ensure((size_t)Qf * 4));
     MM_TRY(ix->qmap64.ensure((size_t)Qf * 8));
     MM_TRY(ix->qs2.ensure((size_t)Qfp * D * ix->qelt()));
-    MM_TRY(ix->cand2.ensure((size_t)Qf * CAPF * 4));
-    MM_TRY(ix->cur2_s.ensure((size_t)Qf * 4));
-    MM_TRY(ix->cur2_r.ensure((size_t)Qf * 4));
-    std::vector<float> inf((size_t)Qf, INFINITY);
-    std::vector<int32_t> neg((size_t)Qf, -1);
+    MM_TRY(ix->thr2.ensure((size_t)Qfp * 4));
+    MM_TRY(ix->swp_cnt.ensure((size_t)Qfp * 4));
+    MM_TRY(ix->swp_list.ensure((size_t)Qf * SWEEP_CAP * 4));
     MM_HIP(hipMemcpyAsync(ix->qmap.p, which.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
     MM_HIP(hipMemcpyAsync(ix->qmap64.p, map64.data(), (size_t)Qf * 8, hipMemcpyHostToDevice, st));
-    MM_HIP(hipMemcpyAsync(ix->cur2_s.p, inf.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
-    MM_HIP(hipMemcpyAsync(ix->cur2_r.p, neg.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
-    MM_HIP(hipMemsetAsync(ix->qs2.p, 0, (size_t)Qfp * D * ix->qelt(), st));
-    MM_HIP(hipMemsetAsync(ix->cand2.p, 0xff, (size_t)Qf * CAPF * 4, st));  // all -1
+    MM_HIP(hipMemsetAsync(ix->swp_cnt.p, 0, (size_t)Qfp * 4, st));
+    if (Qfp > Qf) MM_HIP(hipMemsetAsync(ix->qs2.as<char>() + (size_t)Qf * D * ix->qelt(), 0, (size_t)(Qfp - Qf) * D * ix->qelt(), st));
     {
         const int grid = (int)std::min<int64_t>(4096, ((int64_t)Qf * D + 255) / 256);
         if (ix->dtype != MMISS_F32)   // (f16 query operand for f16 and fp8 rows)
@@ -577,58 +620,76 @@ int widen_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
             hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, st, ix->qs.as<float>(),
                                ix->qmap64.as<int64_t>(), ix->qs2.as<float>(), (int64_t)Qf, D);
         MM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((Qf + 255) / 256), dim3(256), 0, st, ix->thr.as<float>(),
+                           ix->qmap64.as<int64_t>(), ix->thr2.as<float>(), (int64_t)Qf, 1);
+        MM_HIP(hipGetLastError());
     }
-    MM_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
-    const ScanPlan p = plan_scan(D, ix->qelt(), Qf, KP, N);
-    MM_TRY(ix->lists_s.ensure((size_t)p.slabs * Qf * KP * 4));
-    MM_TRY(ix->lists_r.ensure((size_t)p.slabs * Qf * KP * 4));
-    const int pmax = (CAPF - kkpad) / KP;
-    int pages = kkpad / KP + 1;  // first round: room for k results and one page of slack
-    for (int round = 0;; ++round) {
-        if (pages > pmax) pages = pmax;
-        for (int page = 0; page < pages; ++page) {
-            ScanArgs a{};
-            a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = ix->qs2.p; a.Q = Qf;
-            a.cur_s = ix->cur2_s.as<float>(); a.cur_r = ix->cur2_r.as<int32_t>();
-            a.kp = KP; a.tiles_per_block = p.tiles_per_block;
-            a.out_s = ix->lists_s.as<float>(); a.out_r = ix->lists_r.as<int32_t>();
-            MM_TRY(launch_scan(ix, st, a, p));
-            MergeArgs m{};
-            m.in_s = ix->lists_s.as<float>(); m.in_r = ix->lists_r.as<int32_t>();
-            m.L = p.slabs; m.Q = Qf; m.kp = KP;
-            m.cand = ix->cand2.as<int32_t>(); m.cand_stride = CAPF; m.page_off = kkpad + page * KP;
-            m.cur_s = ix->cur2_s.as<float>(); m.cur_r = ix->cur2_r.as<int32_t>();
-            MM_TRY(launch_merge(ix, st, m));
+    if (gemm) {
+        const int64_t Npad = round_up(N, 256), nbn = Npad / 256;
+        GemmEpi ep{};
+        ep.m_valid = Qf; ep.p0 = (int)N; ep.m_fast = 1;
+        StripFilter flt{};
+        flt.tau = ix->thr2.as<float>(); flt.tau_stride = 1; flt.cnt = ix->swp_cnt.as<int32_t>();
+        flt.buf_s = nullptr; flt.buf_g = ix->swp_list.as<int32_t>(); flt.cap = SWEEP_CAP; flt.bn_begin = 0;
+        const int strip = strip_length(Qfp, nbn, nbn);
+        MM_PROF("sweep_gemm_f16", st, 2.0 * Qf * (double)N * D, (double)N * D * 2);
+        MM_TRY((launch_gemm256s<_Float16>(st, ix->qs2.p, ix->rows.p, ep, Qfp, (int)Npad, D, strip, &flt)));
+        ix->stat_pages += 1;
+    } else {
+        ScanArgs a{};
+        a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = ix->qs2.p; a.Q = Qf;
+        a.thr = ix->thr2.as<float>(); a.gcnt = ix->swp_cnt.as<int32_t>(); a.glist = ix->swp_list.as<int32_t>(); a.gcap = SWEEP_CAP;
+        const int nqt = Qf > 32 ? 4 : Qf > 16 ? 2 : 1;
+        const int NQ = 16 * nqt;
+        const int lds = ((NQ * (D * ix->qelt() + 16)) + 15) & ~15;
+        const int qtiles = (Qf + NQ - 1) / NQ;
+        const int64_t ntiles = (N + 15) / 16;
+        const int per_cu = std::max(1, std::min(8, 160 * 1024 / lds));
+        int64_t target = std::max<int64_t>(1, (int64_t)256 * per_cu / qtiles);
+        int64_t tpb = std::max<int64_t>(4, (((ntiles + target - 1) / target) + 3) / 4 * 4);
+        a.tiles_per_block = (int)tpb;
+        const int slabs = (int)((ntiles + tpb - 1) / tpb);
+        MM_PROF(ix->dtype == MMISS_F16 ? "sweep_scan_f16" : ix->dtype == MMISS_F8 ? "sweep_scan_f8" : "sweep_scan_f32", st,
+                2.0 * Qf * (double)N * D, (double)qtiles * N * D * ix->elt);
+        if (ix->dtype == MMISS_F16) {
+            if (nqt == 4) MM_TRY((launch_scan_thr_t<_Float16, 4>(st, a, slabs, qtiles, lds)));
+            else if (nqt == 2) MM_TRY((launch_scan_thr_t<_Float16, 2>(st, a, slabs, qtiles, lds)));
+            else MM_TRY((launch_scan_thr_t<_Float16, 1>(st, a, slabs, qtiles, lds)));
+        } else if (ix->dtype == MMISS_F8) {
+            if (nqt == 4) MM_TRY((launch_scan_thr_t<F8, 4>(st, a, slabs, qtiles, lds)));
+            else if (nqt == 2) MM_TRY((launch_scan_thr_t<F8, 2>(st, a, slabs, qtiles, lds)));
+            else MM_TRY((launch_scan_thr_t<F8, 1>(st, a, slabs, qtiles, lds)));
+        } else {
+            if (nqt == 4) MM_TRY((launch_scan_thr_t<float, 4>(st, a, slabs, qtiles, lds)));
+            else if (nqt == 2) MM_TRY((launch_scan_thr_t<float, 2>(st, a, slabs, qtiles, lds)));
+            else MM_TRY((launch_scan_thr_t<float, 1>(st, a, slabs, qtiles, lds)));
         }
-        ix->stat_pages += pages;
-        MM_HIP(hipMemsetAsync(ix->nflag_d.p, 0, 4, st));
+        ix->stat_pages += qtiles;
+    }
+    // how many rows each query collected: decides the re-rank's sort size and who overflowed (one small read-back)
+    std::vector<int32_t> cnt((size_t)Qf);
+    MM_HIP(hipMemcpyAsync(cnt.data(), ix->swp_cnt.p, (size_t)Qf * 4, hipMemcpyDeviceToHost, st));
+    MM_HIP(hipStreamSynchronize(st));
+    ix->stat_rounds += 1;
+    std::vector<int32_t> rest;
+    int maxc = 1;
+    for (int b = 0; b < Qf; ++b) {
+        if (cnt[b] > SWEEP_CAP) rest.push_back(which[b]);
+        else { maxc = std::max(maxc, cnt[b]); ix->stat_swept_rows += cnt[b]; }
+    }
+    if ((int)rest.size() < Qf) {
         RerankArgs r{};
-        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand2.as<int32_t>();
-        r.cand_stride = CAPF; r.ncand = kkpad + pages * KP; r.group_mode = 0; r.nrows = N;
+        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->swp_list.as<int32_t>();
+        r.cand_stride = SWEEP_CAP; r.ncand = (int)round_up(maxc, 32); r.cand_cnt = ix->swp_cnt.as<int32_t>();
+        r.group_mode = 0; r.nrows = N;
         r.labels = ix->labels_d.as<int64_t>(); r.k = k;
         r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
-        r.qmap = ix->qmap.as<int32_t>(); r.out_rows = ix->cand2.as<int32_t>();
-        r.tau = ix->cur2_s.as<float>(); r.eps = guard_eps(ix);
-        r.flags = ix->flags.as<int32_t>(); r.nflag = ix->nflag_d.as<int32_t>();
-        MM_TRY(launch_rerank(ix, st, r, Qf));
-        int left = 0;
-        MM_TRY(read_nflag(ix, st, &left));
-        ix->stat_rounds += 1;
-        if (left == 0) return MMISS_OK;
-        if (round >= mmiss_option("widen_rounds", 3)) {
-            // Still unproven after a few rounds: a plateau — more rows within eps of the k-th score than paging can walk in
-            // reasonable time (32 rows per full-index scan). Those queries get the exhaustive canonical pass instead: exact
-            // for any data, one index pass + one host selection per query. (It used to fail after ~175 000 tied rows.)
-            std::vector<int32_t> fl((size_t)Qf);
-            MM_HIP(hipMemcpyAsync(fl.data(), ix->flags.p, (size_t)Qf * 4, hipMemcpyDeviceToHost, st));
-            MM_HIP(hipStreamSynchronize(st));
-            std::vector<int32_t> rest;
-            for (int b = 0; b < Qf; ++b)
-                if (fl[b]) rest.push_back(which[b]);
-            return exhaustive_queries(ix, st, rest, k, d_lab, d_dist, d_cnt);
-        }
-        pages *= 2;
+        r.qmap = ix->qmap.as<int32_t>();
+        MM_TRY(launch_rerank(ix, st, r, Qf));   // (an overflowed query's block re-ranks a truncated list; the exhaustive pass overwrites it)
     }
+    MM_TRY(exhaustive_queries(ix, st, rest, k, d_lab, d_dist, d_cnt));
+    MM_HIP(hipStreamSynchronize(st));
+    return MMISS_OK;
 }
 
 }  // namespace
@@ -682,15 +743,19 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
     }
     MM_TRY(ix->qn.ensure((size_t)Qpad * D * 4));
     MM_TRY(ix->qs.ensure((size_t)Qpad * D * ix->qelt()));
+    MM_TRY(ix->eps_q.ensure((size_t)Qpad * 4));
+    MM_TRY(ix->thr.ensure((size_t)Qpad * 4));
     {
         MM_PROF("prep_queries", st, 4.0 * Q * D, (double)Q * D * (8 + ix->elt));
         const int grid = (Qpad + 3) / 4;
+        double eps_fixed, cnorm;
+        guard_terms(ix, &eps_fixed, &cnorm);
         if (ix->dtype != MMISS_F32)   // (f16 query operand for f16 and fp8 rows)
             hipLaunchKernelGGL(prep_queries_kernel<_Float16>, dim3(grid), dim3(256), 0, st, qsrc, ix->qn.as<float>(),
-                               ix->qs.as<_Float16>(), Q, Qpad, D);
+                               ix->qs.as<_Float16>(), Q, Qpad, D, ix->eps_q.as<float>(), eps_fixed, cnorm);
         else
             hipLaunchKernelGGL(prep_queries_kernel<float>, dim3(grid), dim3(256), 0, st, qsrc, ix->qn.as<float>(),
-                               ix->qs.as<float>(), Q, Qpad, D);
+                               ix->qs.as<float>(), Q, Qpad, D, ix->eps_q.as<float>(), eps_fixed, cnorm);
         MM_HIP(hipGetLastError());
     }
 
@@ -702,10 +767,6 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
     MM_TRY(ix->cur_s.ensure((size_t)Q * 4));
     MM_TRY(ix->cur_r.ensure((size_t)Q * 4));
     const bool guard = N > 0 && mmiss_option("exact_guard", 1) != 0;
-    if (guard) {  // the widen pass keeps its own (device) flags and counter
-        MM_TRY(ix->flags.ensure((size_t)Q * 4));
-        MM_TRY(ix->nflag_d.ensure(64));
-    }
     const int32_t* ovf_cnt = nullptr;  // threshold-filtered selection: per-query append counts and their capacity
     int ovf_cap = 0;
     if (N == 0) {
@@ -737,30 +798,7 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         int strip = 1;
         // the strip kernel on the staggered loop of the persistent encoder GEMM (gemm_bf16_p256.h; round 3): D % 128 == 0
         const bool strip_v3 = mmiss_option("score_strip_v3", 1) != 0 && (D % 128) == 0 && D >= 256;
-        if (big) {
-            // consecutive N-tiles per workgroup: long enough to amortise the pipeline fill, short enough to leave
-            // >= 8 workgroups per CU for balance
-            const int64_t tiles = nbn * (Mq / 256);
-            strip = (int)std::min<int64_t>(32, std::max<int64_t>(1, tiles / 2048));
-            // Round 3: the workgroups of a launch run in rounds of one per CU, and a last round of a few workgroups costs a
-            // whole strip (10M rows x 1024 queries: strip 32 gave 4884 workgroups = 19.08 rounds of 256 -> 5 % of the launch
-            // spent with 18 workgroups on the chip). Among the strip lengths down to half the rule's, take the one whose
-            // rounds x length (+ a quarter tile of pipeline fill per workgroup and round) is smallest.
-            if (strip >= 8 && mmiss_option("score_strip_fit", 1) != 0) {
-                const int64_t ncol = filtered ? nbn - ns_tiles : nbn;   // column tiles of the LONG launch
-                double best = 1e300;
-                int best_s = strip;
-                for (int sl = strip; sl >= strip / 2; --sl) {
-                    const int64_t wgs = (Mq / 256) * ((ncol + sl - 1) / sl);
-                    const int64_t rounds = (wgs + 255) / 256;
-                    const double cost = (double)rounds * (sl + 0.25);
-                    if (cost < best - 1e-9) { best = cost; best_s = sl; }
-                }
-                strip = best_s;
-            }
-            const int forced = mmiss_option("score_strip", 0);
-            if (forced > 0) strip = forced;
-        }
+        if (big) strip = strip_length(Mq, nbn, filtered ? nbn - ns_tiles : nbn);
         {
             MM_PROF(filtered ? "score_gemm_f16_sample" : "score_gemm_f16", st, 2.0 * Q * (double)std::min<int64_t>(N, Ndense) * D,
                     (double)std::min<int64_t>(N, Ndense) * D * 2);
@@ -857,7 +895,8 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         r.labels = ix->labels_d.as<int64_t>(); r.k = k;
         r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
         if (guard) {
-            r.tau = ix->cur_s.as<float>(); r.eps = guard_eps(ix);
+            r.tau = ix->cur_s.as<float>(); r.eps_q = ix->eps_q.as<float>();
+            r.thr_out = ix->thr.as<float>();   // what the widen pass starts from
             r.flags = h_flags; r.nflag = nullptr;  // one plain store per query into the pinned block; counted on the host
             r.force_flag = mmiss_option("guard_force", 0);
             r.ovf_cnt = ovf_cnt; r.ovf_cap = ovf_cap;
@@ -891,7 +930,7 @@ int query_end_locked(mmiss_index* ix) {
             if (pd.h_flags[q]) which.push_back(q);
         if (!which.empty()) {
             ix->stat_flagged += (int64_t)which.size();
-            MM_TRY(widen_queries(ix, st, which, pd.k, pd.d_lab, pd.d_dist, pd.d_cnt));  // returns with the stream drained
+            MM_TRY(sweep_queries(ix, st, which, pd.k, pd.d_lab, pd.d_dist, pd.d_cnt));  // returns with the stream drained
         }
     }
     if (!pd.out_dev) {
@@ -937,12 +976,25 @@ extern "C" int mmiss_index_query_end(mmiss_index* ix) {
     return query_end_locked(ix);
 }
 
+// Drop a query opened with mmiss_index_query_begin without taking its results: waits for the first pass that is queued (its
+// kernels write the caller's output buffers and the handle's scratch), then frees the handle for other calls. A no-op when
+// no query is open.
+extern "C" int mmiss_index_query_abort(mmiss_index* ix) {
+    if (!ix) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_query_abort: null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!ix->pend.active) return MMISS_OK;
+    ix->pend.active = false;
+    MM_TRY(mmiss_use_device(ix->device));
+    MM_HIP(hipEventSynchronize(ix->done_ev));
+    return MMISS_OK;
+}
+
 extern "C" int mmiss_index_guard_stats_ex(mmiss_index* ix, int64_t out[8]) {
     if (!ix || !out) MM_FAIL(MMISS_ERR_ARG, "mmiss_index_guard_stats_ex: null argument");
     std::lock_guard<std::mutex> lk(ix->mu);
     for (int i = 0; i < 8; ++i) out[i] = 0;
     out[0] = ix->stat_queries; out[1] = ix->stat_flagged; out[2] = ix->stat_rounds; out[3] = ix->stat_pages;
-    out[4] = ix->stat_exhaustive;
+    out[4] = ix->stat_exhaustive; out[5] = ix->stat_swept_rows;
     return MMISS_OK;
 }
 

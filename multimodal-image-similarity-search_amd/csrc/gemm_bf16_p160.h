@@ -37,7 +37,10 @@
 // 1 = no MFMAs, 2 = no staging, 4 = no fragment reads. 0 = the kernel.
 // EPI: MMISS_EPI_BIAS_RESID_BF16 (the residual GEMMs) or MMISS_EPI_PATCH_F32 (the patch-embedding GEMM: f32 rows scattered to
 // item * tokens + 1 + patch with the position row added, gemm_bf16.h gemm_epilogue's contract; no bias, no residual).
-template <int EPI, int VARIANT>
+// KT: the K-tile count as a compile-time tag (0 = read K at run time). It exists so that the shapes of one encode are
+// DISTINCT SYMBOLS in rocprofv3's kernel trace and PMC passes — out-projection (K = 768: <9,0,12>) and FC2 (K = 3072: <9,0,48>)
+// were one symbol with a 24-75 us "class average" in round 3 — and gives the K loop a constant trip count.
+template <int EPI, int VARIANT, int KT = 0>
 __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W, int M,
                                                           int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int nbm = M / 160, nbn = N >> 8;
-    const int nt = K / GEMM_BK;  // even (K % 128 == 0)
+    const int nt = KT > 0 ? KT : K / GEMM_BK;  // even (K % 128 == 0)
     const int wg = xcd_remap(blockIdx.x, nbm * nbn);
     int bm, bn;
     tile_order(wg, nbm, nbn, 0, bm, bn);   // n fastest: the column tiles of a row block run side by side on one XCD
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm160p_kernel(const __bf16* __restri
     G160_BARRIER();
     if (wm == 1) G160_BARRIER();  // the lower half runs one barrier behind from here on
 
+#pragma unroll 1   // (nt may be a compile-time constant, KT: the loop stays a loop — one copy of the K-tile triple)
     for (int t = 0; t < nt; t += 3) {
         G160_KTILE(0, 2);
         if (t + 1 < nt) G160_KTILE(1, 0);
@@ -346,6 +350,17 @@ static int launch_gemm160p(hipStream_t st, const void* A, const void* W, const G
     G160_DBG_CASE(1) G160_DBG_CASE(2) G160_DBG_CASE(3) G160_DBG_CASE(4) G160_DBG_CASE(5) G160_DBG_CASE(6) G160_DBG_CASE(7)
 #undef G160_DBG_CASE
 #endif
+#define G160_KT_CASE(KT_)                                                                                                        \
+    if (K == (KT_) * GEMM_BK) {                                                                                                  \
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, 0, KT_>), G160_LDS)); \
+        hipLaunchKernelGGL((gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, 0, KT_>), dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, \
+                           st, reinterpret_cast<const __bf16*>(A), reinterpret_cast<const __bf16*>(W), M, N, K, ep);            \
+        MM_HIP(hipGetLastError());                                                                                              \
+        return MMISS_OK;                                                                                                        \
+    }
+    // the towers' shapes: ViT-B/32 out-projection / FC2 (768, 3072), its text tower (512, 2048), ViT-L/14 (1024, 4096)
+    G160_KT_CASE(12) G160_KT_CASE(48) G160_KT_CASE(8) G160_KT_CASE(32) G160_KT_CASE(16) G160_KT_CASE(64)
+#undef G160_KT_CASE
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, 0>), G160_LDS));
     hipLaunchKernelGGL((gemm160p_kernel<MMISS_EPI_BIAS_RESID_BF16, 0>), dim3((M / 160) * (N / 256)), dim3(512), G160_LDS, st, reinterpret_cast<const __bf16*>(A),
                        reinterpret_cast<const __bf16*>(W), M, N, K, ep);

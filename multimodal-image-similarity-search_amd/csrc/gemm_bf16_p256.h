@@ -503,7 +503,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
 // registers only (16-row group maxima; dense stores or, FILTER, rare threshold-passing appends), so the counted waits never
 // have to allow for it. K = D of the index (a multiple of 128).
 // ------------------------------------------------------------------------------------------------
-template <typename IN, bool FILTER>
+// FILTER: 0 = dense group maxima, 1 = (group maximum, group) appended where the maximum reaches the query's tau, 2 = ROW
+// threshold pass of the widen pass (api_index.hip sweep_queries): every index row whose score reaches tau_q is appended to
+// the query's list flt.buf_g[m][..] (row ids in any order; flt.cnt[m] may run past cap: the excess is dropped and the
+// query goes to the exhaustive pass).
+template <typename IN, int FILTER>
 __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M, int N, int K,
                                                           int strip, GemmEpi ep, StripFilter flt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     const int fr = lane & 15, fg = lane >> 4;
     const int nbm = M >> 8, nbn = N >> 8;
     const int nt = K / GEMM_BK;
-    const int bn_begin = FILTER ? flt.bn_begin : 0;
+    const int bn_begin = FILTER != 0 ? flt.bn_begin : 0;
     const int nstrips = (nbn - bn_begin + strip - 1) / strip;
     const int wg = xcd_remap(blockIdx.x, nbm * nstrips);
     const int sidx = wg / nbm, bm = wg - sidx * nbm;   // m fastest: the M-tiles of one strip run side by side
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     float tau_r[8];  // FILTER: thresholds of this lane's 8 queries, complete before the stream starts
 #pragma unroll
     for (int j = 0; j < 8; ++j) tau_r[j] = INFINITY;
-    if constexpr (FILTER) {
+    if constexpr (FILTER != 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int m = bm * 256 + wm * 128 + j * 16 + fr;
@@ -598,6 +602,30 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
         const int g = (bn * 4 + wn) * 4 + fg;
         const int n0 = bn * 256 + wn * 64 + 4 * fg;
         const bool whole = (bn + 1) * 256 <= ep.p0;
+        if constexpr (FILTER == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = bm * 256 + wm * 128 + j * 16 + fr;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
+                if (mx >= tau_r[j]) {   // rare: some row of this lane's 16 reaches the query's threshold (tau_r = +inf for pad queries)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = n0 + i * 16 + r;
+                            if (acc[i][j][r] >= tau_r[j] && n < ep.p0) {
+                                const int pos = atomicAdd(flt.cnt + m, 1);
+                                if (pos < flt.cap) flt.buf_g[(size_t)m * flt.cap + pos] = n;
+                            }
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float mx = -INFINITY;
@@ -618,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
                     }
             }
             const int m = bm * 256 + wm * 128 + j * 16 + fr;
-            if constexpr (FILTER) {
+            if constexpr (FILTER == 1) {
                 if (mx >= tau_r[j] && mx > -INFINITY) {  // (tau_r = +inf for pad queries; -inf maxima = all-pad groups)
                     const int pos = atomicAdd(flt.cnt + m, 1);
                     if (pos < flt.cap) {
@@ -730,16 +758,23 @@ static int launch_gemm256s(hipStream_t st, const void* A, const void* W, const G
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256s: M=%d N=%d K=%d strip=%d", M, N, K, strip);
     const int nbn = N / 256;
     if (flt) {
-        if (flt->bn_begin < 0 || flt->bn_begin >= nbn || !flt->tau || !flt->cnt || !flt->buf_s || !flt->buf_g || flt->cap <= 0)
+        const bool rows_mode = flt->buf_s == nullptr;   // (the row threshold pass keeps no scores)
+        if (flt->bn_begin < 0 || flt->bn_begin >= nbn || !flt->tau || !flt->cnt || !flt->buf_g || flt->cap <= 0)
             MM_FAIL(MMISS_ERR_ARG, "gemm256s: bad filter");
-        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, true>), G256_LDS));
         const int nwg = (M / 256) * ((nbn - flt->bn_begin + strip - 1) / strip);
-        hipLaunchKernelGGL((gemm256s_kernel<IN, true>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
-                           reinterpret_cast<const IN*>(W), M, N, K, strip, ep, *flt);
+        if (rows_mode) {
+            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 2>), G256_LDS));
+            hipLaunchKernelGGL((gemm256s_kernel<IN, 2>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                               reinterpret_cast<const IN*>(W), M, N, K, strip, ep, *flt);
+        } else {
+            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 1>), G256_LDS));
+            hipLaunchKernelGGL((gemm256s_kernel<IN, 1>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                               reinterpret_cast<const IN*>(W), M, N, K, strip, ep, *flt);
+        }
     } else {
-        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, false>), G256_LDS));
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 0>), G256_LDS));
         const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
-        hipLaunchKernelGGL((gemm256s_kernel<IN, false>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+        hipLaunchKernelGGL((gemm256s_kernel<IN, 0>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
                            reinterpret_cast<const IN*>(W), M, N, K, strip, ep, StripFilter{});
     }
     MM_HIP(hipGetLastError());

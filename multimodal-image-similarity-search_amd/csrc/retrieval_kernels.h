@@ -75,9 +75,14 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 
 // Query preparation: qn = canonical normalisation (f32, used by the rerank), qs = qn in the storage
 // dtype for the scan's MFMA operand, rows [Q, Qpad) zero-filled.
+// eps_q (optional): the exactness guard's per-query bound on |approximate - canonical| score (api_index.hip, "exactness
+// contract"): eps_fixed (accumulation + slack terms, the same for every query) + cnorm * |qs - qn|_2 — what rounding the
+// scan operand to T moves a score by is <(qs - qn), c> <= |qs - qn|_2 |c|_2 (Cauchy-Schwarz; cnorm >= |c|_2 of any stored row),
+// with the ACTUAL rounding error of this query instead of the worst case 2^-11 |q|.
 template <typename T>
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, float* __restrict__ qn,
-                                                           T* __restrict__ qs, int Q, int Qpad, int D) {
+                                                           T* __restrict__ qs, int Q, int Qpad, int D,
+                                                           float* __restrict__ eps_q, double eps_fixed, double cnorm) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= Qpad) return;
@@ -92,11 +97,23 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
         acc = acc + v * v;
     }
     const double nrm = sqrt(wave_butterfly_sum(acc));
+    double dq = 0.0;
     for (int d = lane; d < D; d += 64) {
         float y = (float)((double)x[d] / nrm);
         asm volatile("" : "+v"(y));
+        const T ys = (T)y;
         qn[(size_t)r * D + d] = y;
-        qs[(size_t)r * D + d] = (T)y;
+        qs[(size_t)r * D + d] = ys;
+        const double e = (double)(float)ys - (double)y;
+        dq = dq + e * e;
+    }
+    if (eps_q) {
+        dq = wave_butterfly_sum(dq);
+        // rounded UP: a bound. A NaN / inf query (norm 0 or inf) gets an infinite bound: never "proven", harmless.
+        const double e = (eps_fixed + cnorm * sqrt(dq)) * 1.0001;
+        float ef = (float)e;
+        if ((double)ef < e) ef = nextafterf(ef, INFINITY);
+        if (lane == 0) eps_q[r] = (e == e) ? ef : INFINITY;
     }
 }
 
@@ -179,6 +196,13 @@ struct ScanArgs {
     int tiles_per_block;  // 16-row tiles per slab
     float* out_s;         // [gridDim.x][Q][kp]
     int32_t* out_r;
+    // threshold mode (scan_topk_kernel<.., THR = true>, the widen pass): no lists — every row whose approximate score reaches
+    // thr[q] is appended to glist[q][..] (row ids, any order; gcnt[q] counts them and may run past gcap: the excess is
+    // dropped and the query goes to the exhaustive pass)
+    const float* thr;     // [Q]
+    int32_t* gcnt;        // [Q]
+    int32_t* glist;       // [Q][gcap]
+    int gcap;
 };
 
 template <int NQT, int CAP>
@@ -208,7 +232,7 @@ __device__ __forceinline__ u32x4 scan_row_load(const u32x4* p) {
 #endif
 }
 
-template <typename T, int NQT, int CAP, int GS = 8>
+template <typename T, int NQT, int CAP, int GS = 8, bool THR = false>
 __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ELT = ScanTraits<T>::ELT, QELT = ScanTraits<T>::QELT;
@@ -234,7 +258,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
             *reinterpret_cast<u32x4*>(sQ + qr * L.qstride + c * 16) =
                 *reinterpret_cast<const u32x4*>(qsrc + ((size_t)qr * chunks_per_row + c) * 16);
         }
-        for (int i = lane; i < NQ; i += 64) { cnt[i] = 0; tau[i] = SCAN_NEG_INF; }
+        if constexpr (!THR)
+            for (int i = lane; i < NQ; i += 64) { cnt[i] = 0; tau[i] = SCAN_NEG_INF; }
     }
     __syncthreads();
 
@@ -246,6 +271,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
         const int q = qbase + qt * 16 + fr;
         cur_s[qt] = (a.cur_s && q < a.Q) ? a.cur_s[q] : INFINITY;
         cur_r[qt] = (a.cur_r && q < a.Q) ? a.cur_r[q] : -1;
+        if constexpr (THR) tau_r[qt] = q < a.Q ? a.thr[q] : INFINITY;
     }
 
     // compaction of every list of this wave that is longer than kp (wave-uniform control flow)
@@ -355,6 +381,22 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
             for (; byte0 + 512 <= row_bytes; byte0 += 512) steps(std::integral_constant<int, 8>{}, byte0);
             if (byte0 < row_bytes) steps(std::integral_constant<int, 4>{}, byte0);
         }
+        if constexpr (THR) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                const int q = qbase + qt * 16 + fr;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t row = row0 + 4 * fg + reg;
+                    const float s = acc[qt][reg] * ScanTraits<T>::SCORE_SCALE;
+                    if (q < a.Q && row < a.N && s >= tau_r[qt]) {
+                        const int pos = atomicAdd(a.gcnt + q, 1);
+                        if (pos < a.gcap) a.glist[(size_t)q * a.gcap + pos] = (int)row;
+                    }
+                }
+            }
+            continue;
+        }
         // filter + append
         bool need = false;
 #pragma unroll
@@ -380,6 +422,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
         if (__any(need)) compact_all();
     }
 
+    if constexpr (THR) return;
     // block merge: the 4 waves' lists of one query -> one list of kp, written to out[blockIdx.x][q][:]
     compact_all();
     __syncthreads();
@@ -692,6 +735,11 @@ struct RerankArgs {
     // threshold-filtered selection: a query whose candidate list overflowed (ovf_cnt[q] > ovf_cap) lost candidates: flag it
     const int32_t* ovf_cnt;
     int ovf_cap;
+    const float* eps_q;     // per-query error bound (prep_queries_kernel), indexed by the ORIGINAL query; null: eps
+    // out: the threshold of the widen pass, thr_out[q] = (k-th canonical score) - eps rounded down — every row that can
+    // still belong to the top-k has an approximate score >= it (-inf when fewer than k candidates were valid)
+    float* thr_out;
+    const int32_t* cand_cnt;  // per-block candidate count (widen pass: the appended rows), null: ncand for every block
 };
 
 template <typename T>
@@ -716,10 +764,12 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     // pair partial sums of one lane. Same bits as one row per wave (canon_dot in oracle/), a quarter of the dependent
     // steps, 8- / 16-byte row loads instead of 2- / 4-byte ones, and the query slice read once per four rows.
     const int p16 = lane & 15, sub = lane >> 4;
-    for (int c0 = wave * 4; c0 < a.ncand; c0 += nwaves * 4) {
+    int nc = a.ncand;
+    if (a.cand_cnt) { const int cc = a.cand_cnt[b]; nc = cc < nc ? cc : nc; }
+    for (int c0 = wave * 4; c0 < nc; c0 += nwaves * 4) {
         const int c = c0 + sub;
         int64_t row = -1;
-        if (c < a.ncand) {
+        if (c < nc) {
             if (a.group_mode) {
                 const int g = a.cand[(size_t)b * a.cand_stride + (c >> 4)];
                 if (g >= 0) {
@@ -803,6 +853,7 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
         const int lim = a.k < npow ? a.k : npow;
         for (int i = 0; i < lim; ++i) nvalid += (sr[i] != INT32_MAX);
         a.out_count[q] = nvalid;
+        const double eps = a.eps_q ? (double)a.eps_q[q] : a.eps;
         if (a.flags) {
             int flag = 0;
             const float t = a.tau ? a.tau[b] : SCAN_NEG_INF;
@@ -811,11 +862,21 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
                 else if (a.ovf_cnt && a.ovf_cnt[q] > a.ovf_cap) flag = 1;
                 else {
                     const double ck = 1.0 - (double)sd[k_eff - 1];  // k-th canonical score (its float rounding is inside eps)
-                    if (!(ck - (double)t > a.eps)) flag = 1;
+                    if (!(ck - (double)t > eps)) flag = 1;
                 }
             }
             a.flags[b] = flag;
             if (flag && a.nflag) atomicAdd(a.nflag, 1);
+        }
+        if (a.thr_out) {
+            float thr = SCAN_NEG_INF;
+            if (k_eff > 0 && nvalid >= k_eff) {
+                const double lim = (1.0 - (double)sd[k_eff - 1]) - eps;
+                thr = (float)lim;
+                if ((double)thr > lim) thr = nextafterf(thr, -INFINITY);
+                if (!(lim == lim)) thr = SCAN_NEG_INF;   // (NaN distances: keep everything)
+            }
+            a.thr_out[q] = thr;
         }
     }
 }

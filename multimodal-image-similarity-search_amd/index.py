@@ -134,12 +134,13 @@ class FlatIndex:
         return PendingQuery(self, q, (lab, dist, cnt)) if split else (lab, dist, cnt)
 
     def guard_stats(self) -> dict:
-        """Exactness accounting (mmiss_index_guard_stats): queries served, queries whose first pass could not be proven
-        exact and were widened, widen rounds, extra scan pages, and the queries that ended in the exhaustive canonical pass
-        (a tie plateau too long to page through)."""
+        """Exactness accounting (mmiss_index_guard_stats_ex): queries served, queries whose first pass could not be proven
+        exact and were widened, widen (threshold) passes run, extra passes over the index they cost, the queries that ended in
+        the exhaustive canonical pass (a tie plateau of more than 8192 rows), and the rows the threshold passes re-ranked."""
         out = (C.c_int64 * 8)()
         _lib.check(self._lib.mmiss_index_guard_stats_ex(self._h, out))
-        return {"queries": out[0], "widened": out[1], "rounds": out[2], "pages": out[3], "exhaustive": out[4]}
+        return {"queries": out[0], "widened": out[1], "rounds": out[2], "pages": out[3], "exhaustive": out[4],
+                "swept_rows": out[5]}
 
     # ------------------------------------------------------------------ persistence
     def save(self, path: str) -> None:
@@ -148,8 +149,14 @@ class FlatIndex:
     def load(self, path: str) -> None:
         _lib.check(self._lib.mmiss_index_load(self._h, str(path).encode()))
 
+    def abort_query(self) -> None:
+        """Drop a query opened with query_begin() whose handle was lost (mmiss_index_query_abort); no-op otherwise."""
+        with self._call_lock:
+            _lib.check(self._lib.mmiss_index_query_abort(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
+            self._lib.mmiss_index_query_abort(self._h)   # (an abandoned PendingQuery must not outlive its buffers)
             self._lib.mmiss_index_destroy(self._h)
             self._h = None
 
@@ -169,10 +176,34 @@ class PendingQuery:
     def result(self):
         if not self._done:
             with self._index._call_lock:
+                self._done = True   # (whatever _end returns, the C side has closed the query)
                 _lib.check(self._index._lib.mmiss_index_query_end(self._index._h))
-            self._done = True
             self._q = None
         return self._outs
+
+    def abort(self) -> None:
+        """Give the query up (mmiss_index_query_abort): waits for the queued first pass, delivers nothing, frees the index
+        for other calls. Also what happens when the handle is dropped or leaves a `with` block without result()."""
+        if not self._done:
+            self._done = True
+            idx = self._index
+            if getattr(idx, "_h", None):
+                with idx._call_lock:
+                    idx._lib.mmiss_index_query_abort(idx._h)
+            self._q = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.abort()
+        return False
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:
+            pass
 
 
 def blend(img, txt, weight_image: float, device: int = 0):

@@ -1,5 +1,7 @@
 """Host bookkeeping of FlatCollection / PersistentClient (ids, metadata, persistence, chroma-like return shapes)
 with the numeric index replaced by an oracle-backed stand-in (no GPU here)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -144,3 +146,29 @@ def test_mutations_after_a_torn_journal_tail_survive_the_next_restart(colmod, tm
     assert third.count() == committed + 5                # (was 5: the five acknowledged adds were lost)
     assert third.get(ids=["img_9"])["metadatas"] == [{"n": 9}]
     assert third.query(query_embeddings=v[7:8], n_results=1)["ids"] == [["img_7"]]
+
+
+@pytest.mark.parametrize("torn_bytes", [1, 6, 515])
+def test_a_torn_vector_journal_tail_is_cut_off(colmod, tmp_path, torn_bytes):
+    """a crash in the middle of the VECTOR write (the large one) leaves image-match.journal.N.f32 with a size that
+    is not a multiple of 4 and no commit line for those bytes: np.memmap(float32) used to raise and the collection could not
+    be opened at all. Replay now maps the whole floats only, cuts the file back to the end of the last committed record's
+    vectors, and later appends land 4-aligned behind it and survive the next restart."""
+    client = colmod.PersistentClient(path=str(tmp_path))
+    col = client.create_collection("image-match", metadata={"hnsw:space": "cosine"})
+    v = _vecs(12, seed=21)
+    for i in range(5):
+        col.add(ids=[f"img_{i}"], embeddings=[v[i].tolist()], metadatas=[{"n": i}])
+    jv = tmp_path / f"image-match.journal.{col._index_gen}.f32"
+    good = os.path.getsize(jv)
+    with open(jv, "ab") as f:
+        f.write(b"\x7f" * torn_bytes)                    # the torn vectors of an add that never got its commit line
+    second = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert second.count() == 5 and os.path.getsize(jv) == good
+    for i in range(5, 9):
+        second.add(ids=[f"img_{i}"], embeddings=[v[i].tolist()], metadatas=[{"n": i}])
+    assert os.path.getsize(jv) == good // 5 * 9
+    third = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert third.count() == 9
+    assert third.query(query_embeddings=v[7:8], n_results=1)["ids"] == [["img_7"]]
+    assert third.query(query_embeddings=v[2:3], n_results=1)["ids"] == [["img_2"]]

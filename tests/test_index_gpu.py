@@ -431,6 +431,43 @@ def test_query_begin_end_equals_query(mods, device_io, force_widen):
     torch.cuda.synchronize()
 
 
+def test_an_abandoned_query_handle_does_not_wedge_the_index(mods, tmp_path):
+    """a query opened with query_begin whose handle is lost (an exception in the serving loop before
+    result()) used to leave every other entry point refusing with MMISS_ERR_STATE until destroy. The handle now aborts the
+    query when it is dropped, leaves a `with` block, or on abort(); mmiss_index_query_abort itself is a no-op without an
+    open query; add / save / query work afterwards."""
+    from mmiss_amd import _lib
+
+    FlatIndex, _, _, ro = mods
+    N, D, k = 5000, 256, 10
+    c = _corpus(N, D, seed=81)
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    q = _corpus(8, D, seed=82)
+    _lib.check(idx._lib.mmiss_index_query_abort(idx._h))        # nothing open: fine
+    h = idx.query_begin(q, k)
+    with pytest.raises(RuntimeError, match="still open"):
+        idx.save(str(tmp_path / "i.bin"))
+    del h                                                       # the lost handle
+    idx.add(c[:3] * 2.0, np.arange(3, dtype=np.int64) + N)
+    idx.save(str(tmp_path / "i.bin"))
+    with pytest.raises(ZeroDivisionError):
+        with idx.query_begin(q, k):                             # an exception between the two halves
+            1 / 0
+    h = idx.query_begin(q, k)
+    h.abort()
+    h.abort()                                                   # idempotent
+    with pytest.raises(RuntimeError, match="no query was begun"):
+        _lib.check(idx._lib.mmiss_index_query_end(idx._h))
+    c2 = np.concatenate([c, c[:3] * 2.0])
+    lab2 = np.concatenate([labels, np.arange(3, dtype=np.int64) + N])
+    _check(idx, ro, ro.normalize_rows(c2, "f16"), lab2, q, k)
+    h = idx.query_begin(q, k)                                   # close() with a query still open
+    idx.close()
+    del h
+
+
 def test_fp8_rows_rank_like_the_f32_rows_up_to_their_quantisation(mods):
     """MMISS_F8 storage (e4m3 codes of 128 x, include/mmiss.h): the index is exact with respect to its STORED rows (the tests
     above, against the oracle's restatement of the rounding); against the unquantised rows the stored rows lie within a few
