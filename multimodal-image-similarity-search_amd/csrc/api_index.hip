@@ -590,8 +590,8 @@ int strip_length(int Mq, int64_t nbn, int64_t ncol) {
 // (thr_q = c_k - eps_q, left in ix->thr by the first pass's re-rank), the canonical re-rank of the rows it collected, and the
 // exhaustive pass for the lists that overflowed. Results overwrite the queries' rows of d_lab / d_dist / d_cnt. Returns with
 // the stream drained.
-int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& which, int k, int64_t* d_lab, float* d_dist,
-                  int32_t* d_cnt) {
+int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& which, int Q_all, int k, int64_t* d_lab,
+                  float* d_dist, int32_t* d_cnt) {
     const int Qf = (int)which.size(), D = ix->dim;
     const int64_t N = ix->count;
     if (Qf == 0 || N <= 0) return MMISS_OK;
@@ -600,18 +600,25 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
     const bool gemm = ix->dtype == MMISS_F16 && (D % 128) == 0 && D >= 256 && Qf > mmiss_option("sweep_gemm_min_q", 64) &&
                       mmiss_option("score_strip_v3", 1) != 0;
     const int Qfp = (int)round_up(Qf, 256);
-    std::vector<int64_t> map64(which.begin(), which.end());
-    MM_TRY(ix->qmap.ensure((size_t)Qf * 4));
-    MM_TRY(ix->qmap64.ensure((size_t)Qf * 8));
-    MM_TRY(ix->qs2.ensure((size_t)Qfp * D * ix->qelt()));
-    MM_TRY(ix->thr2.ensure((size_t)Qfp * 4));
     MM_TRY(ix->swp_cnt.ensure((size_t)Qfp * 4));
     MM_TRY(ix->swp_list.ensure((size_t)Qf * SWEEP_CAP * 4));
-    MM_HIP(hipMemcpyAsync(ix->qmap.p, which.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
-    MM_HIP(hipMemcpyAsync(ix->qmap64.p, map64.data(), (size_t)Qf * 8, hipMemcpyHostToDevice, st));
     MM_HIP(hipMemsetAsync(ix->swp_cnt.p, 0, (size_t)Qfp * 4, st));
-    if (Qfp > Qf) MM_HIP(hipMemsetAsync(ix->qs2.as<char>() + (size_t)Qf * D * ix->qelt(), 0, (size_t)(Qfp - Qf) * D * ix->qelt(), st));
-    {
+    // Every query of the call flagged (the encoder's own embeddings as the index: all of them, every call): the first pass's
+    // operands are the sweep's operands — no gather, no map, nothing crosses PCIe. Otherwise the flagged queries are compacted.
+    const bool all = Qf == Q_all;
+    const void* qs_sw = ix->qs.p;          // [>= Qfp rows][D] scan operand (rows >= Qf are zero or masked by thr = +inf)
+    const float* thr_sw = ix->thr.as<float>();
+    const int32_t* qmap_sw = nullptr;
+    if (!all) {
+        std::vector<int64_t> map64(which.begin(), which.end());
+        MM_TRY(ix->qmap.ensure((size_t)Qf * 4));
+        MM_TRY(ix->qmap64.ensure((size_t)Qf * 8));
+        MM_TRY(ix->qs2.ensure((size_t)Qfp * D * ix->qelt()));
+        MM_TRY(ix->thr2.ensure((size_t)Qfp * 4));
+        MM_HIP(hipMemcpyAsync(ix->qmap.p, which.data(), (size_t)Qf * 4, hipMemcpyHostToDevice, st));
+        MM_HIP(hipMemcpyAsync(ix->qmap64.p, map64.data(), (size_t)Qf * 8, hipMemcpyHostToDevice, st));
+        MM_HIP(hipStreamSynchronize(st));   // (pageable sources: `map64` goes out of scope)
+        if (Qfp > Qf) MM_HIP(hipMemsetAsync(ix->qs2.as<char>() + (size_t)Qf * D * ix->qelt(), 0, (size_t)(Qfp - Qf) * D * ix->qelt(), st));
         const int grid = (int)std::min<int64_t>(4096, ((int64_t)Qf * D + 255) / 256);
         if (ix->dtype != MMISS_F32)   // (f16 query operand for f16 and fp8 rows)
             hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->qs.as<_Float16>(),
@@ -623,22 +630,23 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
         hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((Qf + 255) / 256), dim3(256), 0, st, ix->thr.as<float>(),
                            ix->qmap64.as<int64_t>(), ix->thr2.as<float>(), (int64_t)Qf, 1);
         MM_HIP(hipGetLastError());
+        qs_sw = ix->qs2.p; thr_sw = ix->thr2.as<float>(); qmap_sw = ix->qmap.as<int32_t>();
     }
     if (gemm) {
         const int64_t Npad = round_up(N, 256), nbn = Npad / 256;
         GemmEpi ep{};
         ep.m_valid = Qf; ep.p0 = (int)N; ep.m_fast = 1;
         StripFilter flt{};
-        flt.tau = ix->thr2.as<float>(); flt.tau_stride = 1; flt.cnt = ix->swp_cnt.as<int32_t>();
+        flt.tau = thr_sw; flt.tau_stride = 1; flt.cnt = ix->swp_cnt.as<int32_t>();
         flt.buf_s = nullptr; flt.buf_g = ix->swp_list.as<int32_t>(); flt.cap = SWEEP_CAP; flt.bn_begin = 0;
         const int strip = strip_length(Qfp, nbn, nbn);
         MM_PROF("sweep_gemm_f16", st, 2.0 * Qf * (double)N * D, (double)N * D * 2);
-        MM_TRY((launch_gemm256s<_Float16>(st, ix->qs2.p, ix->rows.p, ep, Qfp, (int)Npad, D, strip, &flt)));
+        MM_TRY((launch_gemm256s<_Float16>(st, qs_sw, ix->rows.p, ep, Qfp, (int)Npad, D, strip, &flt)));
         ix->stat_pages += 1;
     } else {
         ScanArgs a{};
-        a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = ix->qs2.p; a.Q = Qf;
-        a.thr = ix->thr2.as<float>(); a.gcnt = ix->swp_cnt.as<int32_t>(); a.glist = ix->swp_list.as<int32_t>(); a.gcap = SWEEP_CAP;
+        a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = qs_sw; a.Q = Qf;
+        a.thr = thr_sw; a.gcnt = ix->swp_cnt.as<int32_t>(); a.glist = ix->swp_list.as<int32_t>(); a.gcap = SWEEP_CAP;
         const int nqt = Qf > 32 ? 4 : Qf > 16 ? 2 : 1;
         const int NQ = 16 * nqt;
         const int lds = ((NQ * (D * ix->qelt() + 16)) + 15) & ~15;
@@ -666,26 +674,45 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
         }
         ix->stat_pages += qtiles;
     }
-    // how many rows each query collected: decides the re-rank's sort size and who overflowed (one small read-back)
+    // Re-rank what was collected. The typical list is short (tens to hundreds of rows), so the first launch sorts at most
+    // SWEEP_FAST rows per query WITHOUT waiting to learn the counts; the counts come back with it (one small copy behind the
+    // kernels, one wait), and only the queries that collected more get a second, larger launch — or, past SWEEP_CAP, the
+    // exhaustive pass.
+    const int SWEEP_FAST = 1024;
+    RerankArgs r{};
+    r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->swp_list.as<int32_t>();
+    r.cand_stride = SWEEP_CAP; r.ncand = SWEEP_FAST; r.cand_cnt = ix->swp_cnt.as<int32_t>();
+    r.group_mode = 0; r.nrows = N;
+    r.labels = ix->labels_d.as<int64_t>(); r.k = k;
+    r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
+    r.qmap = qmap_sw;
+    MM_TRY(launch_rerank(ix, st, r, Qf));
     std::vector<int32_t> cnt((size_t)Qf);
     MM_HIP(hipMemcpyAsync(cnt.data(), ix->swp_cnt.p, (size_t)Qf * 4, hipMemcpyDeviceToHost, st));
     MM_HIP(hipStreamSynchronize(st));
     ix->stat_rounds += 1;
-    std::vector<int32_t> rest;
+    std::vector<int32_t> big_b, rest;   // blocks that need the large re-rank / original indices for the exhaustive pass
     int maxc = 1;
     for (int b = 0; b < Qf; ++b) {
         if (cnt[b] > SWEEP_CAP) rest.push_back(which[b]);
-        else { maxc = std::max(maxc, cnt[b]); ix->stat_swept_rows += cnt[b]; }
+        else {
+            ix->stat_swept_rows += cnt[b];
+            if (cnt[b] > SWEEP_FAST) { big_b.push_back(b); maxc = std::max(maxc, cnt[b]); }
+        }
     }
-    if ((int)rest.size() < Qf) {
-        RerankArgs r{};
-        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->swp_list.as<int32_t>();
-        r.cand_stride = SWEEP_CAP; r.ncand = (int)round_up(maxc, 32); r.cand_cnt = ix->swp_cnt.as<int32_t>();
-        r.group_mode = 0; r.nrows = N;
-        r.labels = ix->labels_d.as<int64_t>(); r.k = k;
-        r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
-        r.qmap = ix->qmap.as<int32_t>();
-        MM_TRY(launch_rerank(ix, st, r, Qf));   // (an overflowed query's block re-ranks a truncated list; the exhaustive pass overwrites it)
+    if (!big_b.empty()) {
+        // block j of this launch = block big_b[j] of the sweep: its list and count by bmap, its query by qmap
+        const int nb = (int)big_b.size();
+        std::vector<int32_t> qm((size_t)nb);
+        for (int j = 0; j < nb; ++j) qm[j] = which[big_b[j]];
+        MM_TRY(ix->cand2.ensure((size_t)nb * 8));
+        MM_HIP(hipMemcpyAsync(ix->cand2.p, big_b.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+        MM_HIP(hipMemcpyAsync(ix->cand2.as<int32_t>() + nb, qm.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+        MM_HIP(hipStreamSynchronize(st));
+        r.ncand = (int)round_up(maxc, 32);
+        r.bmap = ix->cand2.as<int32_t>();
+        r.qmap = ix->cand2.as<int32_t>() + nb;
+        MM_TRY(launch_rerank(ix, st, r, nb));
     }
     MM_TRY(exhaustive_queries(ix, st, rest, k, d_lab, d_dist, d_cnt));
     MM_HIP(hipStreamSynchronize(st));
@@ -930,7 +957,7 @@ int query_end_locked(mmiss_index* ix) {
             if (pd.h_flags[q]) which.push_back(q);
         if (!which.empty()) {
             ix->stat_flagged += (int64_t)which.size();
-            MM_TRY(sweep_queries(ix, st, which, pd.k, pd.d_lab, pd.d_dist, pd.d_cnt));  // returns with the stream drained
+            MM_TRY(sweep_queries(ix, st, which, pd.Q, pd.k, pd.d_lab, pd.d_dist, pd.d_cnt));  // returns with the stream drained
         }
     }
     if (!pd.out_dev) {

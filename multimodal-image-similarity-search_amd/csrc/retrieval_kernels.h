@@ -740,19 +740,24 @@ struct RerankArgs {
     // still belong to the top-k has an approximate score >= it (-inf when fewer than k candidates were valid)
     float* thr_out;
     const int32_t* cand_cnt;  // per-block candidate count (widen pass: the appended rows), null: ncand for every block
+    const int32_t* bmap;      // block b reads candidate list / count bmap[b] (null: b)
 };
 
 template <typename T>
 __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // sort buffer: npow2 entries of (dist f32, row i32)
-    int npow = 1;
-    while (npow < a.ncand) npow <<= 1;
-    float* sd = reinterpret_cast<float*>(smem);
-    int32_t* sr = reinterpret_cast<int32_t*>(smem + (size_t)npow * 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int q = a.qmap ? a.qmap[b] : b;
+    const int lb = a.bmap ? a.bmap[b] : b;   // which candidate list
+    int nc = a.ncand;                        // candidates of THIS block (block-uniform)
+    if (a.cand_cnt) { const int cc = a.cand_cnt[lb]; nc = cc < nc ? cc : nc; }
+    // sort buffer: npow2 entries of (dist f32, row i32), sized by the block's own candidate count (the launch provides LDS for
+    // a.ncand): a widened query that collected 60 rows sorts 64 entries, not the launch's 1024
+    int npow = 1;
+    while (npow < nc) npow <<= 1;
+    float* sd = reinterpret_cast<float*>(smem);
+    int32_t* sr = reinterpret_cast<int32_t*>(smem + (size_t)npow * 4);
     const float* qv = a.qn + (size_t)q * a.D;
     const int nthreads = blockDim.x, nwaves = blockDim.x >> 6;
     for (int i = tid; i < npow; i += nthreads) { sd[i] = INFINITY; sr[i] = INT32_MAX; }
@@ -764,20 +769,18 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     // pair partial sums of one lane. Same bits as one row per wave (canon_dot in oracle/), a quarter of the dependent
     // steps, 8- / 16-byte row loads instead of 2- / 4-byte ones, and the query slice read once per four rows.
     const int p16 = lane & 15, sub = lane >> 4;
-    int nc = a.ncand;
-    if (a.cand_cnt) { const int cc = a.cand_cnt[b]; nc = cc < nc ? cc : nc; }
     for (int c0 = wave * 4; c0 < nc; c0 += nwaves * 4) {
         const int c = c0 + sub;
         int64_t row = -1;
         if (c < nc) {
             if (a.group_mode) {
-                const int g = a.cand[(size_t)b * a.cand_stride + (c >> 4)];
+                const int g = a.cand[(size_t)lb * a.cand_stride + (c >> 4)];
                 if (g >= 0) {
                     row = groupmax_row(g, c & 15);
                     if (row >= a.nrows) row = -1;
                 }
             } else {
-                row = a.cand[(size_t)b * a.cand_stride + c];
+                row = a.cand[(size_t)lb * a.cand_stride + c];
             }
         }
         const bool live = row >= 0;  // (no candidate, or an empty index: nothing is dereferenced)
