@@ -880,8 +880,8 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
             n = min(chunk, N - r0)
             idxf.add(torch.randn(n, D, device=dev, generator=gen8), np.arange(r0, r0 + n, dtype=np.int64))
         f8 = {"rows": N, "dim": D, "dtype": "f8 (e4m3 x 2^7)", "k": K_TOP}
-        for Q, iters in ((1, 20), (16, 10)):
-            q = torch.randn(Q, D, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+        for Q, iters in ((1, 20), (16, 10), (1024, 3)):
+            q = q_all[:Q].contiguous()
             idxf.query(q, K_TOP)
             torch.cuda.synchronize()
             _lib.prof_reset()
@@ -892,8 +892,15 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / iters
             _lib.prof_enable(False)
-            sc = {p["kernel"]: p for p in _lib.prof_read()}.get("scan_topk_f8")
+            pr8 = {p["kernel"]: p for p in _lib.prof_read()}
+            sc = pr8.get("scan_topk_f8")
             f8[f"Q{Q}"] = {"ms_per_batch": round(dt * 1e3, 3), "mvec_per_s": round(N / dt / 1e6, 1)}
+            sg8 = pr8.get("score_gemm_f8")
+            if sg8:   # Q = 1024: the strip score GEMM on fp8 rows (codes widened to f16 in the operand load)
+                tfl8 = sg8["flops"] / sg8["ms"] / 1e9
+                f8[f"Q{Q}"]["score_gemm"] = {"avg_ms": round(sg8["ms"] / sg8["launches"], 4), "tflops": round(tfl8, 1),
+                                             "mfma_frac": round(tfl8 / MFMA_BF16_PEAK_TFLOPS, 4)}
+                f8[f"Q{Q}"]["kernel_ms"] = {k_: round(p_["ms"] / iters, 4) for k_, p_ in pr8.items()}
             if sc:
                 sms = sc["ms"] / sc["launches"]
                 f8[f"Q{Q}"]["scan_kernel"] = {"avg_ms": round(sms, 4), "hbm_gbs": round(N * D / sms / 1e6, 1),

@@ -45,9 +45,12 @@ enum {
 
 /* index storage dtypes. MMISS_F8: one byte per element, OCP e4m3 with the fixed scale 2^7 — a stored element is
  * decode(byte) / 128; a unit-norm row has |x_i| <= 1, so 128 x_i fits e4m3 and a typical component keeps its 3 mantissa bits.
- * Distances are exact (canonical fp64) with respect to the STORED rows, as for f16; the stored rows themselves are 2^-4-coarse,
- * so an fp8 index ranks like the f32 / f16 one only up to that quantisation (~1e-2 in cosine). Queries of any batch size
- * take the streaming scan (half the bytes of f16 per row), not the score-GEMM path. */
+ * Distances are exact (canonical fp64) with respect to the STORED rows, as for f16; the stored rows themselves are 2^-4-coarse
+ * and are NOT renormalised after the rounding (|stored row| is within 3 % of 1), so what an fp8 index returns is
+ * 1 - |stored| cos(query, stored), not a cosine distance: it ranks like the f32 / f16 index only up to that quantisation
+ * (~1e-2 in cosine; rows closer together than that — e.g. one encoder's own embeddings — may swap, and a row need not rank
+ * first for its own unquantised vector). Queries of any batch size take the streaming scan (half the bytes of f16 per row),
+ * not the score-GEMM path. */
 enum { MMISS_F32 = 0, MMISS_F16 = 1, MMISS_F8 = 2 };
 
 typedef struct mmiss_encoder mmiss_encoder;

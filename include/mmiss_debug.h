@@ -78,6 +78,13 @@ int mmiss_dbg_quantize_weights_fp8(int device, void* hip_stream, const void* w_b
                                    int32_t K);
 int mmiss_dbg_layernorm_mxfp8(int device, void* hip_stream, const float* x, const float* gamma, const float* beta,
                               void* out8, void* out_scale, int32_t M, int32_t d, float eps);
+/* the same from bf16 rows (the bf16 residual stream of the large calls) */
+int mmiss_dbg_layernorm16_mxfp8(int device, void* hip_stream, const void* x_bf16, const float* gamma, const float* beta,
+                                void* out8, void* out_scale, int32_t M, int32_t d, float eps);
+/* attention whose output leaves the kernel as MXFP8 (the fp8 out-projection's A operand): qkv bf16 [B*T, 3*H*64] -> ctx8 e4m3
+ * [B*T, H*64] + ctx_scale (permuted E8M0, 16 * ceil(H*64 / 512) bytes per row); non-causal, 129 <= T <= 288 */
+int mmiss_dbg_attention_mx(int device, void* hip_stream, const void* qkv, void* ctx8, void* ctx_scale, int32_t B, int32_t T,
+                           int32_t H);
 /* epi: 0 out bf16 = acc * wscale[n] + bias[n]; 1 out e4m3 + out_scale = mx(quick_gelu(.)); 2 out f32 += . ; bm = 128 | 160 | 192 */
 int mmiss_dbg_gemm8(int device, void* hip_stream, int epi, int bm, const void* A8, const void* As, const void* W8,
                     const float* wscale, const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K);

@@ -110,6 +110,8 @@ SIGNATURES = {
     "mmiss_dbg_build_flags": (_I, []),
     "mmiss_dbg_quantize_weights_fp8": (_I, [_I, _P, _P, _P, _P, _I32, _I32]),
     "mmiss_dbg_layernorm_mxfp8": (_I, [_I, _P, _P, _P, _P, _P, _P, _I32, _I32, C.c_float]),
+    "mmiss_dbg_layernorm16_mxfp8": (_I, [_I, _P, _P, _P, _P, _P, _P, _I32, _I32, C.c_float]),
+    "mmiss_dbg_attention_mx": (_I, [_I, _P, _P, _P, _P, _I32, _I32, _I32]),
     "mmiss_dbg_gemm8": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32]),
     "mmiss_dbg_gemm8_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.POINTER(C.c_float)]),
     "mmiss_dbg_gemm_split_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.POINTER(C.c_float)]),

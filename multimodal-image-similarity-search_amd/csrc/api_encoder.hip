@@ -5,9 +5,6 @@
 #include "gemm_bf16_256.h"
 #include "gemm_bf16_p256.h"
 #include "gemm_bf16_p160.h"
-#ifdef MMISS_EXPERIMENTS
-#include "gemm_bf16_ring.h"  // measured-slower alternatives, kept for A/B in debug builds (make EXPERIMENTS=1)
-#endif
 #include "gemm_fp8.h"
 #include "encoder_kernels.h"
 #include "preprocess_kernels.h"
@@ -55,6 +52,7 @@ struct LayerW {
     DevBuf wqkv, bqkv, wo, bo, ln1g, ln1b, ln2g, ln2b, w1, b1, w2, b2;
     DevBuf wqkv_f, cqkv, bqkv_f, w1_f, c1, b1_f;  // LayerNorm folded into the QKV / FC1 weights (finalize)
     DevBuf wqkv8, sqkv, w1_8, s1, w2_8, s2;       // fp8 path: e4m3 weights + per-output-channel f32 scales
+    DevBuf wo8, so;                               // ... of the out-projection (used when the attention output is MXFP8)
 };
 
 struct Tower {
@@ -70,9 +68,11 @@ struct Tower {
     bool embed_stats = false;       // this call's embedding stage already left xb + row statistics (layernorm_stats_kernel)
     DevBuf xc, hc, ctxc, uc;  // compact [Bp, *] buffers of the pooled rows (last-layer pruning)
     DevBuf stats;             // [Mp][hidden/64][2] partial row (sum, sumsq) for the LayerNorm-fused GEMMs
+    DevBuf stats_final;       // [Mp][2] finished (mean, rstd): hidden > 768 on the persistent GEMM (ln_finalize_kernel)
     DevBuf xb;                // bf16 copy of the residual stream (A operand of the LayerNorm-folded GEMMs)
     DevBuf splitk;            // f32 partial products of the split-K GEMMs (middle batch sizes), allocated on demand
     DevBuf h8, hs, u8, us;    // fp8 path: MXFP8 LayerNorm output / FC1 output (e4m3 bytes + permuted E8M0 block scales)
+    DevBuf ctx8, ctxs;        // fp8 path: MXFP8 attention output (the out-projection's A operand)
     bool fp8_ready = false;   // fp8 weights built for this tower
     bool pooled_compact = false;
     int last_B = 0, last_T = 0;
@@ -236,11 +236,14 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     MM_TRY(alloc_zero(tw.uc, (size_t)Bp * tw.mlp * 2));
     MM_TRY(alloc_zero(tw.stats, (size_t)Mp * (d / 16) * 2 * 4));  // (one partial per 64 columns; per 16 in the skinny folded mode)
     MM_TRY(alloc_zero(tw.xb, (size_t)Mp * d * 2));
+    if (d > 768) MM_TRY(alloc_zero(tw.stats_final, (size_t)Mp * 2 * 4));
     if (e->fp8_tower[&tw == &e->txt ? 1 : 0]) {
         MM_TRY(alloc_zero(tw.h8, (size_t)Mp * d));
         MM_TRY(alloc_zero(tw.hs, (size_t)Mp * mx_scale_row_bytes(d)));
         MM_TRY(alloc_zero(tw.u8, (size_t)Mp * tw.mlp));
         MM_TRY(alloc_zero(tw.us, (size_t)Mp * mx_scale_row_bytes(tw.mlp)));
+        MM_TRY(alloc_zero(tw.ctx8, (size_t)Mp * d));
+        MM_TRY(alloc_zero(tw.ctxs, (size_t)Mp * mx_scale_row_bytes(d)));
     }
     if (e->record_taps) {
         tw.tap_stride = Mp * d;
@@ -256,7 +259,10 @@ static int pick_ln_mode(const mmiss_encoder* e, const Tower& tw, int M, bool& fp
     int mode = e->ln_mode;
     if (mode < 0) {
         const int forced = mmiss_option("ln_mode", -1);
-        mode = forced >= 0 ? forced : ((M >= mmiss_option("ln_fold_min_rows", 6000) && tw.hidden <= 768) ? 2 : 0);
+        // (hidden 1024 — ViT-L/14 — folds since round 4: finished row statistics in front of the persistent GEMM; option
+        // ln_fold_1024 = 0 gives the separate LayerNorm kernels back)
+        const int max_hidden = mmiss_option("ln_fold_1024", 1) != 0 ? 1024 : 768;
+        mode = forced >= 0 ? forced : ((M >= mmiss_option("ln_fold_min_rows", 6000) && tw.hidden <= max_hidden) ? 2 : 0);
     }
     fp8 = e->fp8_tower[&tw == &e->txt ? 1 : 0] && tw.fp8_ready && tw.h8.p && M >= mmiss_option("fp8_min_rows", 1024);
     if (fp8) mode = 0;  // the fp8 GEMMs take their A operand from the MXFP8 LayerNorm kernel
@@ -301,9 +307,18 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // epilogue in registers. Taken for the wide GEMMs (QKV, FC1) of calls with at least 256 tiles (one per CU); option
     // gemm_p256 = 0 turns it off, n > 1 = minimum tile count.
     const int p256_min = mmiss_option("gemm_p256", 1);
+    const bool fold_final = d > 768;   // the folded persistent GEMM takes FINISHED (mean, rstd) per row (tw.stats_final)
     auto p256 = [&](int epi, int N) {
-        if (p256_min == 0 || !gemm256p_ok(epi, padded(256), N, d)) return false;
+        const bool is_fold = epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16;
+        if (p256_min == 0 || !gemm256p_ok(epi, padded(256), N, d, is_fold && fold_final && tw.stats_final.p)) return false;
         return (int64_t)(padded(256) / 256) * (N / 256) >= (p256_min > 1 ? p256_min : 256);
+    };
+    auto finalize_stats = [&]() -> int {   // partial (sum, sumsq) per 64 columns -> (mean, rstd) per row
+        MM_PROF("ln_finalize", st, 4.0 * M * (d / 64), (double)M * ((d / 64) * 8 + 8));
+        hipLaunchKernelGGL(ln_finalize_kernel, dim3((M * 8 + 255) / 256), dim3(256), 0, st, tw.stats.as<float>(),
+                           tw.stats_final.as<float>(), M, d / 64, d, eps);
+        MM_HIP(hipGetLastError());
+        return MMISS_OK;
     };
     // The residual GEMMs on the bf16 stream (out-projection, FC2) on the 160 x 256 tile of the two-phase staggered loop
     // (gemm_bf16_p160.h, round 3) when that grid is about one round of the chip, or K is long: isolated, ViT-B/32 bs 256
@@ -375,18 +390,13 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
             if (p256(MMISS_EPI_LNFOLD_BF16, 3 * d)) {
+                if (fold_final) { MM_TRY(finalize_stats()); ep.ln_final = tw.stats_final.as<float>(); }
                 MM_TRY(launch_gemm256p(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, padded(256), 3 * d, d));
             } else if (fold256(3 * d)) {
                 MM_TRY(launch_gemm256(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, padded(256), 3 * d, d));
             } else {
                 MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_BF16, bm_qkv, tw.xb.p, L.wqkv_f.p, ep, padded(bm_qkv), 3 * d, d));
             }
-#ifdef MMISS_EXPERIMENTS
-        } else if (fuse) {
-            ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln1g.as<float>(); ep.ln_b = L.ln1b.as<float>();
-            ep.ln_parts = parts; ep.ln_eps = eps;
-            MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.x.as<float>(), L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
-#endif
         } else if (fp8) {
             MM_TRY(launch_layernorm_mxfp8(st, resid16 ? tw.xb.p : tw.x.p, resid16, L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h8.as<uint8_t>(),
                                           tw.hs.as<uint8_t>(), M, d, eps));
@@ -408,6 +418,14 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             else if (use256(3 * d)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_BF16, tw.h.p, L.wqkv.p, ep, padded(256), 3 * d, d));
             else MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
         }
+        // fp8 tower, long sequences (ViT-L/14): the attention output leaves the kernel as MXFP8 and the out-projection runs
+        // on the fp8 GEMM too (round 4; option fp8_outproj = 0: bf16 ctx + bf16 out-projection as in round 3). Not in the
+        // pruned last layer (its out-projection is a 128-row bf16 GEMM on gathered rows).
+        const bool last_pruned = prune && l == tw.layers - 1;
+        const bool out8 = fp8 && !causal && !last_pruned && resid16 && L.wo8.p && tw.ctx8.p && attention_mx_ok(tw.T, tw.heads) &&
+                          mmiss_option("fp8_outproj", 1) != 0;
+        if (out8) MM_TRY(launch_attention_mx(st, tw.qkv.p, tw.ctx8.as<uint8_t>(), tw.ctxs.as<uint8_t>(), mx_scale_row_bytes(d), B, tw.T, tw.heads));
+        else
         MM_TRY(launch_attention(st, tw.qkv.p, tw.ctx.p, B, tw.T, tw.heads, causal));
         if (prune && l == tw.layers - 1) {
             const int Bp = (int)round_up(B, 128);
@@ -436,7 +454,13 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         ep.stats_out = (fuse || fold || sfold) ? tw.stats.as<float>() : nullptr;  // row statistics of the new residual for LN2
         ep.xb_out = (fold || sfold) ? tw.xb.p : nullptr;
         ep.stats16 = sfold ? 1 : 0;
-        if (resid16) {  // the bf16 rows ARE the residual stream: read-modify-write in place, no f32 stream
+        if (out8) {
+            Gemm8Args g{};
+            g.A = tw.ctx8.as<uint8_t>(); g.As = tw.ctxs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
+            g.W = L.wo8.as<uint8_t>(); g.wscale = L.so.as<float>(); g.bias = L.bo.as<float>();
+            g.out = tw.xb.p; g.ldo = d; g.M = padded(bm8_d); g.N = d; g.K = d; g.m_valid = M;
+            MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_RESID_BF16, bm8_d, g));
+        } else if (resid16) {  // the bf16 rows ARE the residual stream: read-modify-write in place, no f32 stream
             ep.out = tw.xb.p; ep.xb_out = nullptr;
             if (p160(d, d)) MM_TRY(launch_gemm160p(st, tw.ctx.p, L.wo.p, ep, padded(160), d, d));
             else MM_TRY(launch_gemm_resid16(st, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
@@ -449,18 +473,13 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
             if (p256(MMISS_EPI_LNFOLD_QGELU_BF16, tw.mlp)) {
+                if (fold_final) { MM_TRY(finalize_stats()); ep.ln_final = tw.stats_final.as<float>(); }
                 MM_TRY(launch_gemm256p(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, padded(256), tw.mlp, d));
             } else if (fold256(tw.mlp) && mmiss_option("gemm_256_fold_mlp", 0)) {  // (A/B knob: 78 -> 84 us at 12 800 rows, off)
                 MM_TRY(launch_gemm256(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, padded(256), tw.mlp, d));
             } else {
                 MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, bm_mlp, tw.xb.p, L.w1_f.p, ep, padded(bm_mlp), tw.mlp, d));
             }
-#ifdef MMISS_EXPERIMENTS
-        } else if (fuse) {
-            ep.ln_stats = tw.stats.as<float>(); ep.ln_g = L.ln2g.as<float>(); ep.ln_b = L.ln2b.as<float>();
-            ep.ln_parts = parts; ep.ln_eps = eps;
-            MM_TRY(launch_gemm_ln(st, MMISS_EPI_BIAS_QGELU_BF16, bm_mlp, tw.x.as<float>(), L.w1.p, ep, padded(bm_mlp), tw.mlp, d));
-#endif
         } else if (fp8) {
             // LN2 -> MXFP8, FC1 + QuickGELU -> MXFP8 (per row and 64 columns), FC2 + residual: `u` crosses HBM as 1 byte
             MM_TRY(launch_layernorm_mxfp8(st, resid16 ? tw.xb.p : tw.x.p, resid16, L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h8.as<uint8_t>(),
@@ -882,6 +901,7 @@ static int build_fp8_weights(mmiss_encoder* enc) {
             MM_TRY(quant(L.wqkv, L.wqkv8, L.sqkv, 3 * d, d));
             MM_TRY(quant(L.w1, L.w1_8, L.s1, mlp, d));
             MM_TRY(quant(L.w2, L.w2_8, L.s2, d, mlp));
+            MM_TRY(quant(L.wo, L.wo8, L.so, d, d));
         }
         tw->fp8_ready = true;
     }
@@ -1138,10 +1158,8 @@ extern "C" int mmiss_encode_text(mmiss_encoder* enc, const int32_t* ids, int32_t
 extern "C" int mmiss_dbg_encoder_set_fuse_ln(mmiss_encoder* enc, int on) {
     if (!enc) MM_FAIL(MMISS_ERR_ARG, "null encoder");
     std::lock_guard<std::mutex> lk(enc->mu);
-#ifndef MMISS_EXPERIMENTS
-    if (on == 1) MM_FAIL(MMISS_ERR_UNSUPPORTED, "LayerNorm mode 1 (normalise while staging) exists only in builds with MMISS_EXPERIMENTS");
-#endif
-    enc->ln_mode = on < 0 ? -1 : (on > 2 ? 2 : on);  // -1 automatic, 0 separate kernels, 1 operand-fused, 2 folded
+    if (on == 1) MM_FAIL(MMISS_ERR_UNSUPPORTED, "LayerNorm mode 1 (normalised during operand staging) was removed in round 4: measured 342-371 TF, profiles/gemm_variants_r01.md");
+    enc->ln_mode = on < 0 ? -1 : (on > 2 ? 2 : on);  // -1 automatic, 0 separate kernels, 2 folded
     return MMISS_OK;
 }
 
@@ -1216,11 +1234,7 @@ extern "C" int mmiss_dbg_gemm(int device, void* hip_stream, int epi, int variant
         ep.splitk_ws = dbg_splitk.as<float>(); ep.splitk_ws_bytes = dbg_splitk.bytes;
     }
     if (variant == 256) return launch_gemm256(reinterpret_cast<hipStream_t>(hip_stream), epi, A, W, ep, M, N, K);
-#ifdef MMISS_EXPERIMENTS
-    if (variant > 1000 && variant < 2000) return launch_gemm_ring(reinterpret_cast<hipStream_t>(hip_stream), epi, variant - 1000, A, W, ep, M, N, K);
-#else
-    if (variant > 1000) MM_FAIL(MMISS_ERR_UNSUPPORTED, "GEMM variant %d exists only in builds with MMISS_EXPERIMENTS (make EXPERIMENTS=1)", variant);
-#endif
+    if (variant > 1000) MM_FAIL(MMISS_ERR_UNSUPPORTED, "GEMM variant %d (ring pipeline / BM x 256 tiles) was removed in round 4: measured slower, profiles/gemm_variants_r01.md", variant);
     return launch_gemm(reinterpret_cast<hipStream_t>(hip_stream), epi, variant, A, W, ep, M, N, K);
 }
 
@@ -1295,11 +1309,7 @@ extern "C" int mmiss_dbg_gemm_time(int device, int epi, int variant, const void*
     MM_HIP(hipEventCreate(&e1));
     auto run = [&]() -> int {
         if (variant == 256) return launch_gemm256(nullptr, epi, A, W, ep, M, N, K);
-#ifdef MMISS_EXPERIMENTS
-        if (variant > 1000 && variant < 2000) return launch_gemm_ring(nullptr, epi, variant - 1000, A, W, ep, M, N, K);
-#else
-        if (variant > 1000) MM_FAIL(MMISS_ERR_UNSUPPORTED, "GEMM variant %d exists only in builds with MMISS_EXPERIMENTS", variant);
-#endif
+        if (variant > 1000) MM_FAIL(MMISS_ERR_UNSUPPORTED, "GEMM variant %d was removed in round 4", variant);
         return launch_gemm(nullptr, epi, variant, A, W, ep, M, N, K);
     };
     for (int i = 0; i < 3; ++i) MM_TRY(run());
@@ -1394,6 +1404,26 @@ extern "C" int mmiss_dbg_quantize_weights_fp8(int device, void* hip_stream, cons
                        reinterpret_cast<const uint16_t*>(w_bf16), reinterpret_cast<uint8_t*>(w8), scale, N, K);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
+}
+
+// bf16 rows in (the bf16 residual stream): d = 512 / 1024 take the wide kernel of round 4, other d the first form
+extern "C" int mmiss_dbg_layernorm16_mxfp8(int device, void* hip_stream, const void* x_bf16, const float* gamma, const float* beta,
+                                           void* out8, void* out_scale, int32_t M, int32_t d, float eps) {
+    if (!x_bf16 || !gamma || !beta || !out8 || !out_scale) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_layernorm16_mxfp8: null pointer");
+    if (M <= 0) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_layernorm16_mxfp8: M = %d", M);
+    MM_TRY(mmiss_use_device(device));
+    return launch_layernorm_mxfp8(reinterpret_cast<hipStream_t>(hip_stream), x_bf16, true, gamma, beta,
+                                  reinterpret_cast<uint8_t*>(out8), reinterpret_cast<uint8_t*>(out_scale), M, d, eps);
+}
+
+// qkv bf16 [B*T, 3*H*64] -> the attention output as MXFP8: ctx8 e4m3 [B*T, H*64] + permuted E8M0 scales [B*T, 16 * ceil(H*64 / 512)]
+// (non-causal, 129 <= T <= 288: the long-sequence form)
+extern "C" int mmiss_dbg_attention_mx(int device, void* hip_stream, const void* qkv, void* ctx8, void* ctx_scale, int32_t B,
+                                      int32_t T, int32_t H) {
+    if (!qkv || !ctx8 || !ctx_scale) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_attention_mx: null pointer");
+    MM_TRY(mmiss_use_device(device));
+    return launch_attention_mx(reinterpret_cast<hipStream_t>(hip_stream), qkv, reinterpret_cast<uint8_t*>(ctx8),
+                               reinterpret_cast<uint8_t*>(ctx_scale), mx_scale_row_bytes(H * 64), B, T, H);
 }
 
 extern "C" int mmiss_dbg_layernorm_mxfp8(int device, void* hip_stream, const float* x, const float* gamma, const float* beta,

@@ -49,6 +49,8 @@ struct mmiss_index {
         int64_t* out_labels = nullptr; float* out_dist = nullptr; int32_t* out_count = nullptr;
     } pend;
     DevBuf dist_all;  // exhaustive fallback: one canonical distance per row
+    float* dist_pin = nullptr;   // ... and the pinned host block they come back through
+    int64_t dist_pin_rows = 0;
     hipStream_t stream() const { return has_user_stream ? user_stream : own_stream; }
 };
 
@@ -187,7 +189,7 @@ int launch_scan(mmiss_index* ix, hipStream_t st, const ScanArgs& a, const ScanPl
 // merge L per-slab lists of every query into its candidate page; above 64 lists in two levels so that a single
 // query (the API path) is not merged by one lone workgroup
 int launch_merge(mmiss_index* ix, hipStream_t st, MergeArgs m) {
-    if (m.L > 64) {
+    if (m.L > mmiss_option("merge_two_level_min", 64)) {
         const int per = 32;
         const int S = (m.L + per - 1) / per;
         MM_TRY(ix->lists2_s.ensure((size_t)S * m.Q * m.kp * 4));
@@ -249,6 +251,7 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
     (void)hipDeviceSynchronize();
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     if (ix->pin) (void)hipHostFree(ix->pin);
+    if (ix->dist_pin) (void)hipHostFree(ix->dist_pin);
     if (ix->done_ev) (void)hipEventDestroy(ix->done_ev);
     delete ix;
     return MMISS_OK;
@@ -514,14 +517,20 @@ int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_
     const int D = ix->dim, KP = 32;
     const int kk = (int)std::min<int64_t>(k, N);
     const int kkpad = (int)round_up(std::max(kk, 1), KP);
-    if (which.empty() || N <= 0) return MMISS_OK;
+    const int nq = (int)which.size();
+    if (nq == 0 || N <= 0) return MMISS_OK;
     MM_TRY(ix->dist_all.ensure((size_t)N * 4));
-    MM_TRY(ix->cand2.ensure((size_t)kkpad * 4));
-    MM_TRY(ix->qmap.ensure(4));
-    std::vector<float> dist((size_t)N);
-    std::vector<int32_t> cand((size_t)kkpad);
+    // the distances come back through a PINNED block (a pageable destination makes the copy synchronous and slow: ADVICE r3)
+    if (ix->dist_pin_rows < N) {
+        if (ix->dist_pin) { MM_HIP(hipHostFree(ix->dist_pin)); ix->dist_pin = nullptr; ix->dist_pin_rows = 0; }
+        MM_HIP(hipHostMalloc(reinterpret_cast<void**>(&ix->dist_pin), (size_t)N * 4, hipHostMallocDefault));
+        ix->dist_pin_rows = N;
+    }
+    const float* dist = ix->dist_pin;
+    std::vector<int32_t> cand((size_t)nq * kkpad, -1);
     typedef std::pair<float, int32_t> Ent;  // (distance, row); NaN distances never enter
-    for (const int32_t q : which) {
+    for (int i = 0; i < nq; ++i) {
+        const int32_t q = which[i];
         {
             MM_PROF("canonical_scan", st, 2.0 * N * D, (double)N * D * ix->elt);
             const int grid = (int)std::min<int64_t>(8192, (N + 15) / 16);
@@ -536,7 +545,7 @@ int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_
                                    ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
             MM_HIP(hipGetLastError());
         }
-        MM_HIP(hipMemcpyAsync(dist.data(), ix->dist_all.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        MM_HIP(hipMemcpyAsync(ix->dist_pin, ix->dist_all.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
         MM_HIP(hipStreamSynchronize(st));
         std::priority_queue<Ent> heap;  // max-heap: top = the worst of the best kk so far, by (distance, row)
         for (int64_t r = 0; r < N; ++r) {
@@ -545,20 +554,23 @@ int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_
             if ((int)heap.size() < kk) heap.push(Ent(d, (int32_t)r));
             else if (Ent(d, (int32_t)r) < heap.top()) { heap.pop(); heap.push(Ent(d, (int32_t)r)); }
         }
-        std::fill(cand.begin(), cand.end(), -1);
-        for (size_t i = 0; !heap.empty(); ++i) { cand[i] = heap.top().second; heap.pop(); }
-        MM_HIP(hipMemcpyAsync(ix->cand2.p, cand.data(), (size_t)kkpad * 4, hipMemcpyHostToDevice, st));
-        MM_HIP(hipMemcpyAsync(ix->qmap.p, &q, 4, hipMemcpyHostToDevice, st));
-        RerankArgs r{};
-        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand2.as<int32_t>();
-        r.cand_stride = kkpad; r.ncand = kkpad; r.group_mode = 0; r.nrows = N;
-        r.labels = ix->labels_d.as<int64_t>(); r.k = k;
-        r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
-        r.qmap = ix->qmap.as<int32_t>();
-        MM_TRY(launch_rerank(ix, st, r, 1));
-        MM_HIP(hipStreamSynchronize(st));  // `q` and `cand` are reused by the next query
+        int32_t* c = cand.data() + (size_t)i * kkpad;
+        for (size_t j = 0; !heap.empty(); ++j) { c[j] = heap.top().second; heap.pop(); }
         ix->stat_exhaustive += 1;
     }
+    // ONE re-rank launch for all of them (final ordering, labels, counts): block b = query which[b], its kkpad selected rows
+    MM_TRY(ix->cand2.ensure((size_t)nq * kkpad * 4));
+    MM_TRY(ix->qmap.ensure((size_t)nq * 4));
+    MM_HIP(hipMemcpyAsync(ix->cand2.p, cand.data(), (size_t)nq * kkpad * 4, hipMemcpyHostToDevice, st));
+    MM_HIP(hipMemcpyAsync(ix->qmap.p, which.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    RerankArgs r{};
+    r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand2.as<int32_t>();
+    r.cand_stride = kkpad; r.ncand = kkpad; r.group_mode = 0; r.nrows = N;
+    r.labels = ix->labels_d.as<int64_t>(); r.k = k;
+    r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
+    r.qmap = ix->qmap.as<int32_t>();
+    MM_TRY(launch_rerank(ix, st, r, nq));
+    MM_HIP(hipStreamSynchronize(st));  // (`cand` and `which` leave scope with the caller)
     return MMISS_OK;
 }
 
@@ -597,7 +609,8 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
     if (Qf == 0 || N <= 0) return MMISS_OK;
     // the score GEMM for an f16 index once the flagged queries fill a quarter of a 256-query tile (it costs about what 1.2
     // streaming scans cost, and a scan serves 64 queries), the scan otherwise
-    const bool gemm = ix->dtype == MMISS_F16 && (D % 128) == 0 && D >= 256 && Qf > mmiss_option("sweep_gemm_min_q", 64) &&
+    const bool gemm8 = ix->dtype == MMISS_F8 && mmiss_option("score_f8_gemm", 1) != 0;
+    const bool gemm = (ix->dtype == MMISS_F16 || gemm8) && (D % 128) == 0 && D >= 256 && Qf > mmiss_option("sweep_gemm_min_q", 64) &&
                       mmiss_option("score_strip_v3", 1) != 0;
     const int Qfp = (int)round_up(Qf, 256);
     MM_TRY(ix->swp_cnt.ensure((size_t)Qfp * 4));
@@ -640,8 +653,9 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
         flt.tau = thr_sw; flt.tau_stride = 1; flt.cnt = ix->swp_cnt.as<int32_t>();
         flt.buf_s = nullptr; flt.buf_g = ix->swp_list.as<int32_t>(); flt.cap = SWEEP_CAP; flt.bn_begin = 0;
         const int strip = strip_length(Qfp, nbn, nbn);
-        MM_PROF("sweep_gemm_f16", st, 2.0 * Qf * (double)N * D, (double)N * D * 2);
-        MM_TRY((launch_gemm256s<_Float16>(st, qs_sw, ix->rows.p, ep, Qfp, (int)Npad, D, strip, &flt)));
+        MM_PROF(gemm8 ? "sweep_gemm_f8" : "sweep_gemm_f16", st, 2.0 * Qf * (double)N * D, (double)N * D * ix->elt);
+        if (gemm8) MM_TRY((launch_gemm256s<_Float16, true>(st, qs_sw, ix->rows.p, ep, Qfp, (int)Npad, D, strip, &flt)));
+        else MM_TRY((launch_gemm256s<_Float16>(st, qs_sw, ix->rows.p, ep, Qfp, (int)Npad, D, strip, &flt)));
         ix->stat_pages += 1;
     } else {
         ScanArgs a{};
@@ -787,7 +801,11 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
     }
 
     // batched path: f16 rows, more than one MFMA tile of queries, single page
-    const bool dense = (N > 0) && ix->dtype == MMISS_F16 && Q > 16 && pages == 1;
+    // ... and fp8 rows from two 128-query tiles on (round 4: the strip kernel widens the codes to f16 in its operand load —
+    // gemm256s_kernel<_Float16, .., W8>; below that the streaming scan, which reads half the bytes per row, is the faster)
+    const bool dense8 = (N > 0) && ix->dtype == MMISS_F8 && pages == 1 && Q >= mmiss_option("score_big_min_q", 129) &&
+                        (D % 128) == 0 && D >= 256 && mmiss_option("score_strip_v3", 1) != 0 && mmiss_option("score_f8_gemm", 1) != 0;
+    const bool dense = ((N > 0) && ix->dtype == MMISS_F16 && Q > 16 && pages == 1) || dense8;
     MM_TRY(ix->cand.ensure((size_t)Q * ncand * 4));
     // (score, row) of the last candidate stage 1 kept per query, -inf when it kept every row: the paging cursor, and the
     // guard's bound on what was left out
@@ -814,7 +832,7 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         // It costs four extra small launches (~35 us), so it is taken when the matrix it avoids is worth more: from
         // Q x N = 10^9 scores (256 MB of group maxima written and read back). Option score_filter: 0 never, 2 whenever possible.
         const int64_t nbn = Npad / 256;
-        const int64_t ns_tiles = std::max<int64_t>(16, nbn / mmiss_option("score_sample_div", 32));
+        const int64_t ns_tiles = std::max<int64_t>(16, nbn / std::max(1, mmiss_option("score_sample_div", 32)));
         const int filter_opt = mmiss_option("score_filter", 1);
         const bool filtered = big && nbn >= 128 && filter_opt != 0 && (filter_opt == 2 || (double)Mq * (double)Npad >= 1e9);
         const int64_t Ndense = filtered ? ns_tiles * 256 : Npad;   // rows whose group maxima are materialised
@@ -827,9 +845,11 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         const bool strip_v3 = mmiss_option("score_strip_v3", 1) != 0 && (D % 128) == 0 && D >= 256;
         if (big) strip = strip_length(Mq, nbn, filtered ? nbn - ns_tiles : nbn);
         {
-            MM_PROF(filtered ? "score_gemm_f16_sample" : "score_gemm_f16", st, 2.0 * Q * (double)std::min<int64_t>(N, Ndense) * D,
-                    (double)std::min<int64_t>(N, Ndense) * D * 2);
-            if (big && strip_v3)
+            MM_PROF(dense8 ? (filtered ? "score_gemm_f8_sample" : "score_gemm_f8") : (filtered ? "score_gemm_f16_sample" : "score_gemm_f16"), st,
+                    2.0 * Q * (double)std::min<int64_t>(N, Ndense) * D, (double)std::min<int64_t>(N, Ndense) * D * ix->elt);
+            if (dense8)
+                MM_TRY((launch_gemm256s<_Float16, true>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Ndense, D, strip)));
+            else if (big && strip_v3)
                 MM_TRY((launch_gemm256s<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Ndense, D, strip)));
             else if (big)
                 MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Ndense, D, strip)));
@@ -874,8 +894,9 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
             flt.cnt = ix->fcnt.as<int32_t>(); flt.buf_s = ix->fbuf_s.as<float>(); flt.buf_g = ix->fbuf_g.as<int32_t>();
             flt.cap = cap; flt.bn_begin = (int)ns_tiles;
             {
-                MM_PROF("score_gemm_f16", st, 2.0 * Q * (double)(N - Ndense) * D, (double)(N - Ndense) * D * 2);
-                if (strip_v3) MM_TRY((launch_gemm256s<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
+                MM_PROF(dense8 ? "score_gemm_f8" : "score_gemm_f16", st, 2.0 * Q * (double)(N - Ndense) * D, (double)(N - Ndense) * D * ix->elt);
+                if (dense8) MM_TRY((launch_gemm256s<_Float16, true>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
+                else if (strip_v3) MM_TRY((launch_gemm256s<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
                 else MM_TRY((launch_gemm256_strip<_Float16>(st, ix->qs.p, ix->rows.p, ep, Mq, (int)Npad, D, strip, &flt)));
             }
             m.in_s = ix->seed_s.as<float>(); m.in_r = ix->seed_r.as<int32_t>(); m.L = 1;

@@ -311,6 +311,37 @@ __global__ __launch_bounds__(256) void layernorm_stats_kernel(float* __restrict_
     for (int i = lane; i < parts * 2; i += 64) o[i] = (i == 0) ? ys : (i == 1 ? yq : 0.f);
 }
 
+// (mean, rstd) of every row from its partial (sum, sumsq) per 64 columns — what the folded GEMM's epilogue applies. The
+// persistent kernel finalises a tile's rows itself while K <= 768; for K = 1024 (ViT-L/14) the 32 KB of raw partials of a
+// 256-row tile do not fit beside its staging buffers, so this pass runs in front of it: 128 bytes in, 8 out per row, one
+// thread per row (4 MB per launch at 32 896 rows: a few us against the 25 us LayerNorm kernel it replaces).
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ stats, float* __restrict__ out, int M,
+                                                          int parts, int d, float eps) {
+    // eight lanes per row, one 16-byte load each per 16 partials (consecutive lanes read consecutive bytes), then three
+    // xor-shuffles inside the group of eight
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int r = gid >> 3, l8 = gid & 7;
+    const int rr = r < M ? r : M - 1;
+    const f32x4* st = reinterpret_cast<const f32x4*>(stats + (size_t)rr * parts * 2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = l8; q < parts / 2; q += 8) {
+        const f32x4 v = st[q];
+        s1 += v[0] + v[2];
+        s2 += v[1] + v[3];
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (r < M && l8 == 0) {
+        const float kd = (float)d;
+        const float mean = s1 / kd;
+        const float var = fmaxf(s2 / kd - mean * mean, 0.f);
+        *reinterpret_cast<float2*>(out + 2 * (size_t)r) = make_float2(mean, 1.0f / sqrtf(var + eps));
+    }
+}
+
 // Row statistics for the LayerNorm-fused GEMM (gemm_bf16.h, ALN): stats[r][0] = (sum, sumsq) of row r, the other
 // parts zero. Only needed once per forward (the embeddings); afterwards the residual GEMM epilogues produce them.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
@@ -458,9 +489,15 @@ __device__ __forceinline__ void attention_onepass_tile(const char* sK, const cha
 // long sequences: 8 waves share one staged K/V image. (One wave per pair of query tiles — 9 waves for the 17 tiles of
 // ViT-L/14, so that no wave walks a third pass for the one-row 17th tile — measured SLOWER: 125 vs 101 us per layer.)
 #define ATT_THREADS(NKP) ((NKP) > 4 ? 512 : 256)
-template <int NKP, bool CAUSAL>
+// MXOUT (long-sequence form only; the fp8 vision tower's out-projection on the block-scaled fp8 GEMM, round 4): INSTEAD of
+// the bf16 rows the kernel writes the attention output as MXFP8 — e4m3 bytes ctx8 [B*T, H*64] and one E8M0 scale per
+// (row, 32 columns) in the permuted layout of gemm_fp8.h (ctxs, ld_s bytes per row). A (query, head) holds two 32-column
+// blocks (output rows dt 0,1 / 2,3 of O^T); a lane has 8 values of each, the block maximum is one lane-local maximum and two
+// xor-shuffles over the four lane groups.
+template <int NKP, bool CAUSAL, bool MXOUT = false>
 __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
-                                                        int T, int H) {
+                                                        int T, int H, uint8_t* __restrict__ ctx8 = nullptr,
+                                                        uint8_t* __restrict__ ctxs = nullptr, int ld_s = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKP * 32;
     char* sK = smem;             // [TP][128 B], 16-B chunks XOR-swizzled by (row & 7)
@@ -555,7 +592,14 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mxc = mx * c_exp;
-            float l = 0.f;
+            // The softmax denominator comes from the matrix cores too (round 4): a fifth "row tile" of V^T made of ones —
+            // lacc = 1 * P^T — sums the bf16 P of every key of this lane's query into every register of lacc, with no vector
+            // add per score and no shuffle across the lane groups (the kernel is bound by vector issue, the matrix pipe is
+            // a quarter busy). It is the sum of the ROUNDED probabilities, the ones the PV product uses: the weights of the
+            // output row sum to one exactly.
+            const u32x4 ones_raw = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+            const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_raw);
+            f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
             f32x4 oacc[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -567,15 +611,16 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                 if (2 * ks + 1 < kt_end) p1 = score_tile(2 * ks + 1);
                 else p1 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p0[r], c_exp, -mxc)); l += p0[r]; }
+                for (int r = 0; r < 4; ++r) p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p0[r], c_exp, -mxc));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p1[r], c_exp, -mxc)); l += p1[r]; }
+                for (int r = 0; r < 4; ++r) p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p1[r], c_exp, -mxc));
                 u32x4 praw;
                 praw[0] = pack_bf16x2(p0[0], p0[1]);
                 praw[1] = pack_bf16x2(p0[2], p0[3]);
                 praw[2] = pack_bf16x2(p1[0], p1[1]);
                 praw[3] = pack_bf16x2(p1[2], p1[3]);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
+                lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc, 0, 0, 0);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const char* a0 = sV + (32 * ks + 4 * fg + tq) * ATT_VSTRIDE + (dt * 16 + 4 * tp) * 2;
@@ -589,9 +634,35 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
                 }
             }
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            const float inv = 1.0f / l;
+            const float inv = 1.0f / lacc[0];
+            if constexpr (MXOUT) {
+                const size_t row = (size_t)b * T + (q < T ? q : 0);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    float o[2][4];
+                    float amax = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o[i][r] = oacc[2 * blk + i][r] * inv;
+                            amax = fmaxf(amax, fabsf(o[i][r]));
+                        }
+                    amax = fmaxf(amax, __shfl_xor(amax, 16));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    int e8;
+                    float sinv;
+                    mx_scale_of(amax, e8, sinv);
+                    if (q < T) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            *reinterpret_cast<uint32_t*>(ctx8 + row * dmodel + h * 64 + (2 * blk + i) * 16 + 4 * fg) =
+                                pack_fp8x4(o[i][0] * sinv, o[i][1] * sinv, o[i][2] * sinv, o[i][3] * sinv);
+                        if (fg == 0) ctxs[row * ld_s + mx_scale_offset(2 * h + blk)] = (uint8_t)e8;
+                    }
+                }
+                continue;
+            }
             if (q < T) {
                 uint16_t* orow = ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg;
 #pragma unroll
@@ -761,6 +832,35 @@ static int launch_im2col(hipStream_t st, const void* pixels, bool src_u8, void* 
         hipLaunchKernelGGL(im2col_kernel<false>, dim3(grid), dim3(256), 0, st, pixels, (uint16_t*)out, B, S, P, Kp);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
+}
+
+// the long-sequence form writing MXFP8 (attention_kernel<NKP, false, true>): non-causal only (the vision tower), 129..288 keys
+template <int NKP>
+static int launch_attention_mx_nkp(hipStream_t st, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
+    const int lds = NKP * 32 * (128 + ATT_VSTRIDE);
+    constexpr int NW = ATT_THREADS(NKP) / 64;
+    const int rounds = ((T + 15) / 16 + NW - 1) / NW;
+    int qs = 256 / (B * H);
+    qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<NKP, false, true>), lds));
+    hipLaunchKernelGGL((attention_kernel<NKP, false, true>), dim3(B * H, qs), dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
+                       (uint16_t*)nullptr, T, H, ctx8, ctxs, ld_s);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+static bool attention_mx_ok(int T, int H) { return T > 128 && T <= 288 && H > 0; }
+static int launch_attention_mx(hipStream_t st, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
+    if (B <= 0) return MMISS_OK;
+    if (!attention_mx_ok(T, H) || !ctx8 || !ctxs || ld_s < mx_scale_row_bytes(H * 64))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "attention (MXFP8 output): T=%d (129..288), H=%d", T, H);
+    MM_PROF("attention_mx", st, 4.0 * B * H * (double)T * T * 64, (double)B * T * H * 64 * (2 * 3 + 1));
+    switch ((T + 31) / 32) {
+        case 5: return launch_attention_mx_nkp<5>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
+        case 6: return launch_attention_mx_nkp<6>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
+        case 7: return launch_attention_mx_nkp<7>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
+        case 8: return launch_attention_mx_nkp<8>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
+        default: return launch_attention_mx_nkp<9>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
+    }
 }
 
 template <int NKP>

@@ -41,6 +41,9 @@ struct GemmEpi {
     // split-K (launch_gemm only): f32 scratch for the partial products [splits][M][N]; null = never split
     float* splitk_ws;
     size_t splitk_ws_bytes;
+    // LNFOLD epilogues of the persistent kernel, K > 768: (mean, rstd) of every row FINISHED, [M][2] (ln_finalize_kernel) —
+    // the raw partials of a 256-row tile (K / 64 x 8 bytes per row) no longer fit beside the staging buffers
+    const float* ln_final;
 };
 
 #define MMISS_EPI_GROUPMAX_F32 5  // internal: out f32 [M, N/16] = max over the lane's 16 n (see decode below)
@@ -656,34 +659,10 @@ static inline int gemm_pick_bm(int64_t M_rows, int N) {
     return best;
 }
 
-// Tile VARIANT for launch_gemm: a tile height (128/160/192: BM x 128 tile, 4 waves, 2 workgroups per CU) or 2000 + BM
-// (BM x 256 tile, 8 waves, 1 workgroup per CU: the A panel is staged once per 256 columns). The wide tiles are 3-11 %
-// faster on the ViT-B/32 shapes as ISOLATED launches (160 x 256: QKV 51.8 vs 58.1 us, FC2 62.0 vs 66.8 us) but 8 % slower
-// inside the encode (3.49 vs 3.22 ms, tools/option_ab.py gemm_wide 0 1: a 106 KB-LDS workgroup cannot start on a CU until
-// the previous kernel has left it completely), so they are OFF by default (option gemm_wide = 1 turns the cost model on).
-static inline int gemm_pick_variant(int64_t M_rows, int N) {
-    int best = gemm_pick_bm(M_rows, N);
-#ifndef MMISS_EXPERIMENTS
-    return best;
-#endif
-    if ((N % 256) != 0 || mmiss_option("gemm_wide", 0) == 0) return best;
-    const double effn[3] = {1.00, 0.93, 0.89}, effw[3] = {0.97, 0.86, 0.84};
-    const int bms[3] = {128, 160, 192};
-    double best_cost = 1e300;
-    for (int v = 0; v < 3; ++v)
-        if (bms[v] == best) {
-            const double tiles = (double)((M_rows + best - 1) / best) * (N / GEMM_BN);
-            const double rounds = tiles <= 1024.0 ? (double)((int64_t)((tiles + 511.0) / 512.0)) : tiles / 512.0 + 0.5;
-            best_cost = rounds * best * effn[v];
-        }
-    for (int v = 0; v < 3; ++v) {
-        const double tiles = (double)((M_rows + bms[v] - 1) / bms[v]) * (N / 256);
-        const double rounds = tiles <= 512.0 ? (double)((int64_t)((tiles + 255.0) / 256.0)) : tiles / 256.0 + 0.5;
-        const double cost = rounds * bms[v] * effw[v];
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = 2000 + bms[v]; }
-    }
-    return best;
-}
+// Tile variant for launch_gemm = the tile height (128 / 160 / 192: BM x 128 tile, 4 waves, 2 workgroups per CU). (The BM x 256
+// tiles with 8 waves, variants 2000 + BM of rounds 1-3 — 3-11 % faster as isolated launches, 8 % slower inside the encode —
+// were removed in round 4; profiles/gemm_variants_r01.md.)
+static inline int gemm_pick_variant(int64_t M_rows, int N) { return gemm_pick_bm(M_rows, N); }
 
 template <typename IN, int BM, int EPI, bool ALN = false, int NWN = 2, bool S3 = false, int NWM = 2>
 static int launch_gemm_inst(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K,
@@ -755,32 +734,6 @@ static int launch_gemm_resid16(hipStream_t st, int bm, const void* A, const void
     MM_FAIL(MMISS_ERR_ARG, "gemm_resid16: unsupported tile height %d", bm);
 }
 
-#ifdef MMISS_EXPERIMENTS  // ln_mode 1: measured slower (342-371 TF), kept for A/B in debug builds
-// LayerNorm-fused bf16 GEMM: X f32 [M,K] (the residual stream), ep.ln_* set; epilogues BIAS_BF16 / BIAS_QGELU_BF16.
-static int launch_gemm_ln(hipStream_t st, int epi, int bm, const float* X, const void* W, const GemmEpi& ep, int M, int N,
-                          int K) {
-    if (bm == 0) bm = 128;
-    if (M <= 0 || N <= 0 || K <= 0 || (M % bm) || (N % GEMM_BN) || (K % GEMM_BK) || !ep.ln_stats || !ep.ln_g || !ep.ln_b)
-        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm_ln: M=%d N=%d K=%d bm=%d", M, N, K, bm);
-    const int mv = ep.m_valid < M ? ep.m_valid : M;
-    const double bytes = 4.0 * (double)mv * K + 2.0 * (double)N * K + 2.0 * (double)mv * N;
-    MM_PROF(epi == MMISS_EPI_BIAS_BF16 ? "gemm_ln_bf16_bias" : "gemm_ln_bf16_bias_qgelu", st, 2.0 * mv * N * K, bytes);
-#define GEMM_LN_CASE(BMV)                                                                                          \
-    case BMV:                                                                                                      \
-        return epi == MMISS_EPI_BIAS_BF16                                                                          \
-                   ? launch_gemm_inst<__bf16, BMV, MMISS_EPI_BIAS_BF16, true>(st, X, W, ep, M, N, K)               \
-                   : launch_gemm_inst<__bf16, BMV, MMISS_EPI_BIAS_QGELU_BF16, true>(st, X, W, ep, M, N, K);
-    if (epi != MMISS_EPI_BIAS_BF16 && epi != MMISS_EPI_BIAS_QGELU_BF16) MM_FAIL(MMISS_ERR_ARG, "gemm_ln: epilogue %d", epi);
-    switch (bm) {
-        GEMM_LN_CASE(128)
-        GEMM_LN_CASE(160)
-        GEMM_LN_CASE(192)
-    }
-#undef GEMM_LN_CASE
-    MM_FAIL(MMISS_ERR_ARG, "gemm_ln: unsupported tile height %d", bm);
-}
-
-#endif  // MMISS_EXPERIMENTS
 
 // Two or three staging buffers: a grid of at most 256 workgroups puts one workgroup on a CU whatever its LDS footprint,
 // so the deeper pipeline costs no occupancy there and hides the load latency the second workgroup would have hidden.
@@ -808,12 +761,6 @@ static int launch_gemm_bm(hipStream_t st, int bm, const void* A, const void* W, 
         case 128: return launch_gemm_stages<IN, 128, EPI>(st, A, W, ep, M, N, K);
         case 160: return launch_gemm_stages<IN, 160, EPI>(st, A, W, ep, M, N, K);
         case 192: return launch_gemm_stages<IN, 192, EPI>(st, A, W, ep, M, N, K);
-#ifdef MMISS_EXPERIMENTS
-        // 2000 + BM: the BM x 256 tile with 8 waves (one workgroup per CU): slower inside the encode, debug builds only
-        case 2128: return launch_gemm_inst<IN, 128, EPI, false, 4>(st, A, W, ep, M, N, K);
-        case 2160: return launch_gemm_inst<IN, 160, EPI, false, 4>(st, A, W, ep, M, N, K);
-        case 2192: return launch_gemm_inst<IN, 192, EPI, false, 4>(st, A, W, ep, M, N, K);
-#endif
     }
     MM_FAIL(MMISS_ERR_ARG, "gemm: unsupported tile height %d", bm);
 }

@@ -34,6 +34,23 @@
 #define P256_TABLE (P256_BC + 4096)   // 256 x (mean, rstd)
 #define P256_TILES (P256_TABLE + 2048)  // this workgroup's tile list: 64 x (bm | bn << 16), decoded once before the K stream
 #define P256_RAW (P256_TILES + 256)    // 256 rows x K/64 x (sum, sumsq) f32, as they lie in memory; the epilogue's patches
+#define P256_FTAB (P256_RAW + 16384)   // XP = 1 (finished statistics): 2 x 256 x (mean, rstd) of the current / next tile, behind the patches
+
+// eight e4m3 codes (one lane's 8 consecutive k of an fp8 index row) -> the f16 fragment of the MFMA, exactly (e4m3 fits f16)
+__device__ __forceinline__ f16x8 p256_widen_f8(u32x2 w) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f16x8 r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
+        const f2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
+        const h2 l2 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(lo[0], lo[1]));
+        const h2 g2 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(hi[0], hi[1]));
+        r[4 * i + 0] = l2[0]; r[4 * i + 1] = l2[1]; r[4 * i + 2] = g2[0]; r[4 * i + 3] = g2[1];
+    }
+    return r;
+}
 
 // DBG (timing experiments only, EXPERIMENTS builds, tools/gemm_p256_ablate.py; results are wrong by construction), a
 // compile-time mask: 1 = no MFMAs, 2 = no staging inside the loop, 4 = no fragment reads, 8 = every tile loads tile (0, 0)
@@ -41,7 +58,10 @@
 // STYLE: how the epilogue gets from "a lane holds 4 consecutive columns of one row" to wide stores: 0 = a 16 x 64 transpose
 // per wave through a private 2 KB LDS patch, whole 128-byte rows per store instruction; 1 = two v_permlane16_swap per
 // 16 x 32 block, 8 consecutive columns per lane, 64-byte row segments (two adjacent instructions per line).
-template <int EPI, int XP, int STYLE = 0, int DBG = 0>  // XP = 16-byte statistic pieces per wave and tile (K / 256 when folded, else 0)
+// XP = statistic pieces per wave and tile in the folded modes: K / 256 16-byte pieces of RAW partials (K = 512, 768: finalised
+// in the kernel), or 1 = ONE 4-byte piece of FINISHED (mean, rstd) pairs from ep.ln_final (any K; ln_finalize_kernel ran first);
+// 0 otherwise
+template <int EPI, int XP, int STYLE = 0, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ W, int M,
                                                           int N, int K, GemmEpi ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     constexpr bool FOLD = (EPI == MMISS_EPI_LNFOLD_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
     constexpr bool GELU = (EPI == MMISS_EPI_BIAS_QGELU_BF16 || EPI == MMISS_EPI_LNFOLD_QGELU_BF16);
     static_assert(FOLD == (XP > 0), "statistic pieces exist exactly in the folded modes");
+    constexpr bool FINAL = FOLD && XP == 1;
     constexpr int EX = 16 + 1 + XP;  // vector-memory operations of a wave between two tiles' K streams
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,6 +131,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(A), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(W), 0, 0x7fffffff, 0x00020000);
     const int row8 = 8 * K * 2;  // bytes between a slot's two 8-row pieces
+    const int w_row8 = row8;
+    constexpr bool W8 = false;   // (the retrieval kernel below also takes fp8 index rows as its W operand)
     const int stage_dst = wave * 2048;
 #define P256_SLOT(which, b) (((which) * 2 + (b)) * G256_SLOT)
 #define P256_BLDS(srd, vo, so, dst) \
@@ -131,10 +154,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                 if constexpr (((PCS) & 1) != 0) P256_BLDS4(srdA, a_vo, so_, dst_);                          \
                 if constexpr (((PCS) & 2) != 0) P256_BLDS4(srdA, a_vo, so_ + row8, dst_ + 1024);            \
             }                                                                                               \
+        } else if constexpr (W8) {                                                                          \
+            /* fp8 index rows: a slot is 128 rows x 64 bytes = ONE 16-row piece per wave; the second operation the */ \
+            /* counted waits expect is a 4-byte-per-lane filler into the slot's unused upper half */          \
+            const int so_ = (oW) + ((which) & 1) * 4 * w_row8;                                              \
+            char* dst8_ = smem + P256_SLOT(which, b) + wave * 1024;                                         \
+            if constexpr (((PCS) & 1) != 0) P256_BLDS(srdW, w_vo, so_, dst8_);                              \
+            if constexpr (((PCS) & 2) != 0) P256_BLDS4(srdW, w_vo, so_, smem + P256_SLOT(which, b) + 8192 + wave * 256); \
         } else {                                                                                            \
-            const int so_ = (oW) + ((which) & 1) * 4 * row8;                                                \
+            const int so_ = (oW) + ((which) & 1) * 4 * w_row8;                                              \
             if constexpr (((PCS) & 1) != 0) P256_BLDS(srdW, w_vo, so_, dst_);                               \
-            if constexpr (((PCS) & 2) != 0) P256_BLDS(srdW, w_vo, so_ + row8, dst_ + 1024);                 \
+            if constexpr (((PCS) & 2) != 0) P256_BLDS(srdW, w_vo, so_ + w_row8, dst_ + 1024);               \
         }                                                                                                   \
     }
 // Both pieces of a slot are issued in the read part of the phase. P256_SPLIT_STAGE issues the second one from the middle of
@@ -154,7 +184,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         const float* src = ((FOLD && wave >= 4) ? ep.aux : ep.bias) + bn * 256 + (wave & 3) * 64 + lane;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + P256_BC + par * 2048 + wave * 256), 4, 0, 0);
-        if constexpr (FOLD) {
+        if constexpr (FINAL) {
+            // the tile's 256 x (mean, rstd) = 512 floats, 64 per wave; two tables (as for bias / c): a wave may be here while
+            // another is still in the previous tile's epilogue, reading that tile's table
+            const float* fs = ep.ln_final + (size_t)bm * 512 + wave * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)fs,
+                                             (__attribute__((address_space(3))) void*)(smem + P256_FTAB + par * 2048 + wave * 256), 4, 0, 0);
+        } else if constexpr (FOLD) {
             const char* st = reinterpret_cast<const char*>(ep.ln_stats) + (size_t)bm * 256 * (size_t)(XP * 32) + lane * 16;
 #pragma unroll
             for (int q = 0; q < XP; ++q) glds16(st + (wave * XP + q) * 1024, smem + P256_RAW + (wave * XP + q) * 1024);
@@ -184,7 +220,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         }                                                                                                   \
     }
 #define P256_READ_W(b, nq)                                                                                   \
-    if constexpr (!((DBG & 4) != 0)) {                                                                      \
+    if constexpr (W8) {                                                                                     \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                                  \
+            wq[nq][nf][0] = __builtin_bit_cast(frag, p256_widen_f8(*reinterpret_cast<const u32x2*>(smem + wb[0] + P256_SLOT(nq, b) + nf * 1024))); \
+            wq[nq][nf][1] = __builtin_bit_cast(frag, p256_widen_f8(*reinterpret_cast<const u32x2*>(smem + wb[1] + P256_SLOT(nq, b) + nf * 1024))); \
+        }                                                                                                   \
+    } else if constexpr (!((DBG & 4) != 0)) {                                                               \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                                  \
             wq[nq][nf][0] = *reinterpret_cast<const frag*>(smem + wb[0] + P256_SLOT(nq, b) + nf * 2048);    \
             wq[nq][nf][1] = *reinterpret_cast<const frag*>(smem + wb[1] + P256_SLOT(nq, b) + nf * 2048);    \
@@ -268,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     }
 // (encoder GEMM) K-tile 2 of a tile makes the (mean, rstd) table of the tile's rows in its last, read-free phase
 #define P256_FIN_HOOK(FIN)                                                                                   \
-    if constexpr (FOLD && (FIN)) {                                                                          \
+    if constexpr (FOLD && !FINAL && (FIN)) {                                                                \
         if (kp == 1 && tid < 256) finalize_stats();                                                         \
     }
 // position t+1 becomes the old t+2; t+2 moves on one K-tile (into the next tile, or wraps in the last one)
@@ -350,7 +391,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         for (int j = 0; j < JN; ++j) {
             mu[j] = 0.f; rs[j] = 1.f;
             if constexpr (FOLD) {
-                const float* tb = reinterpret_cast<const float*>(smem + P256_TABLE) + 2 * (wm * 128 + hrow + j * 16 + fr);
+                const float* tb = reinterpret_cast<const float*>(smem + (FINAL ? P256_FTAB + par * 2048 : P256_TABLE)) +
+                                  2 * (wm * 128 + hrow + j * 16 + fr);
                 mu[j] = tb[0]; rs[j] = tb[1];
             }
         }
@@ -491,9 +533,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     if (++k2 == nt) {                                                                                       \
         k2 = 0;                                                                                             \
         if (o2 + 1 < mine) ++o2;                                                                            \
-        oA2 = 0; oW2 = o2 * 256 * K * (int)sizeof(IN);                                                      \
+        oA2 = 0; oW2 = o2 * 256 * K * WELT;                                                                 \
     } else {                                                                                                \
-        oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * (int)sizeof(IN);                                 \
+        oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * WELT;                                            \
     }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,12 +549,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
 // threshold pass of the widen pass (api_index.hip sweep_queries): every index row whose score reaches tau_q is appended to
 // the query's list flt.buf_g[m][..] (row ids in any order; flt.cnt[m] may run past cap: the excess is dropped and the
 // query goes to the exhaustive pass).
-template <typename IN, int FILTER>
-__global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__ A, const IN* __restrict__ W, int M, int N, int K,
+// W8 (round 4): the index rows are fp8 (MMISS_F8: e4m3 codes of 128 x) — half the staged bytes per row. A W slot is then
+// 128 rows x 64 bytes: one 16-row LDS-DMA piece per wave (lane = row * 4 + 16-byte unit, unit XOR-swizzled by (row >> 2) & 3
+// so that the 8-byte fragment reads of rows r, r + 4, r + 8, r + 12 — one bank window — fall on four different chunks), a
+// fragment is one ds_read_b64 widened exactly to f16 in registers (p256_widen_f8), the MFMA stays the f16 one with the f16
+// queries; scores come out times 128 (the codes' fixed scale) and are scaled back where they leave the registers.
+template <typename IN, int FILTER, bool W8 = false>
+__global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__ A, const void* __restrict__ Wv, int M, int N, int K,
                                                           int strip, GemmEpi ep, StripFilter flt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef IN IN_T;
     typedef typename MfmaIn<IN>::frag frag;
+    static_assert(!W8 || std::is_same<IN, _Float16>::value, "fp8 rows are widened to f16");
+    constexpr int WELT = W8 ? 1 : (int)sizeof(IN);
+    constexpr float WSCALE = W8 ? 1.0f / 128.0f : 1.0f;
     constexpr int DBG = 0;
     constexpr bool FOLD = false;
     constexpr int EX = 0;
@@ -530,22 +580,28 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     const int bn0 = bn_begin + sidx * strip;
     const int mine = (nbn - bn0 < strip) ? nbn - bn0 : strip;
     const IN* Ab = A + (size_t)bm * 256 * K;
-    const IN* Wb = W + (size_t)bn0 * 256 * K;          // offsets inside a strip fit 32 bits (strip <= 32 tiles of <= 1 MB)
+    const char* Wb = reinterpret_cast<const char*>(Wv) + (size_t)bn0 * 256 * K * WELT;  // offsets inside a strip fit 32 bits (strip <= 32 tiles of <= 1 MB)
 
     const int r_in = lane >> 3, p = lane & 7;
     const int src_chunk = (p ^ r_in) * 8;
     const int a_vo = (((wave >> 2) * 128 + (wave & 3) * 16 + r_in) * K + src_chunk) * (int)sizeof(IN);
-    const int w_vo = (((wave >> 1) * 64 + (wave & 1) * 16 + r_in) * K + src_chunk) * (int)sizeof(IN);
+    // W slot row r = weight row (r >> 5) * 64 + nq * 32 + (r & 31); a wave stages slot rows 16 * wave .. + 15: as two 8-row
+    // pieces of 128-byte rows (f16), or as ONE piece of sixteen 64-byte rows (fp8: lane = 4 * row + unit)
+    const int r8 = lane >> 2;   // fp8: the lane's row of the piece
+    const int w_vo = W8 ? (((wave >> 1) * 64 + (wave & 1) * 16 + r8) * K + (((lane & 3) ^ ((r8 >> 2) & 3)) << 4))
+                        : (((wave >> 1) * 64 + (wave & 1) * 16 + r_in) * K + src_chunk) * (int)sizeof(IN);
     const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN*>(Ab), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<IN*>(Wb), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, 0x7fffffff, 0x00020000);
     const int row8 = 8 * K * (int)sizeof(IN);
+    const int w_row8 = 8 * K * WELT;
     const int stage_dst = wave * 2048;
     const int mA1 = 8 * row8;
     uint32_t ab[2], wb[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         ab[s] = (wm * 64 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
-        wb[s] = P256_SLOT(2, 0) + (wn * 32 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
+        wb[s] = W8 ? P256_SLOT(2, 0) + (wn * 32 + fr) * 64 + (((4 * s + fg) ^ (2 * ((fr >> 2) & 3))) << 3)
+                   : P256_SLOT(2, 0) + (wn * 32 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
     }
     frag am[4][2];
     frag wq[2][2][2];
@@ -569,20 +625,30 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(tau_r[j]));
     }
 
-    int oA1 = 0, oW1 = 0, oA2 = GEMM_BK * (int)sizeof(IN), oW2 = oA2;
+    int oA1 = 0, oW1 = 0, oA2 = GEMM_BK * (int)sizeof(IN), oW2 = GEMM_BK * WELT;
     int o2 = 0, k2 = 1;
     {
         char* d0 = smem + stage_dst;
+        // (the same two operations per slot and wave as in the loop, in the same order: the counted waits depend on it)
+#define P256_PRO_W(which, b, oW)                                                                                      \
+        if constexpr (W8) {                                                                                          \
+            P256_BLDS(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8, smem + P256_SLOT(which, b) + wave * 1024);      \
+            P256_BLDS4(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8, smem + P256_SLOT(which, b) + 8192 + wave * 256); \
+        } else {                                                                                                     \
+            P256_BLDS(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8, d0 + P256_SLOT(which, b));                      \
+            P256_BLDS(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8 + w_row8, d0 + P256_SLOT(which, b) + 1024);      \
+        }
         P256_BLDS(srdA, a_vo, oA1, d0 + P256_SLOT(0, 0)); P256_BLDS(srdA, a_vo, oA1 + row8, d0 + P256_SLOT(0, 0) + 1024);
-        P256_BLDS(srdW, w_vo, oW1, d0 + P256_SLOT(2, 0)); P256_BLDS(srdW, w_vo, oW1 + row8, d0 + P256_SLOT(2, 0) + 1024);
-        P256_BLDS(srdW, w_vo, oW1 + 4 * row8, d0 + P256_SLOT(3, 0)); P256_BLDS(srdW, w_vo, oW1 + 5 * row8, d0 + P256_SLOT(3, 0) + 1024);
+        P256_PRO_W(2, 0, oW1)
+        P256_PRO_W(3, 0, oW1)
         P256_BLDS(srdA, a_vo, oA1 + mA1, d0 + P256_SLOT(1, 0)); P256_BLDS(srdA, a_vo, oA1 + mA1 + row8, d0 + P256_SLOT(1, 0) + 1024);
         P256_BLDS(srdA, a_vo, oA2, d0 + P256_SLOT(0, 1)); P256_BLDS(srdA, a_vo, oA2 + row8, d0 + P256_SLOT(0, 1) + 1024);
-        P256_BLDS(srdW, w_vo, oW2, d0 + P256_SLOT(2, 1)); P256_BLDS(srdW, w_vo, oW2 + row8, d0 + P256_SLOT(2, 1) + 1024);
-        P256_BLDS(srdW, w_vo, oW2 + 4 * row8, d0 + P256_SLOT(3, 1)); P256_BLDS(srdW, w_vo, oW2 + 5 * row8, d0 + P256_SLOT(3, 1) + 1024);
+        P256_PRO_W(2, 1, oW2)
+        P256_PRO_W(3, 1, oW2)
+#undef P256_PRO_W
     }
     oA1 = oA2; oW1 = oW2;
-    oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * (int)sizeof(IN);
+    oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * WELT;
     k2 = 2;
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     P256_BARRIER();
@@ -609,13 +675,14 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
                 float mx = -INFINITY;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
+                mx *= WSCALE;   // (fp8 rows: the codes are 128 x the stored values; a power of two, exact)
                 if (mx >= tau_r[j]) {   // rare: some row of this lane's 16 reaches the query's threshold (tau_r = +inf for pad queries)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int n = n0 + i * 16 + r;
-                            if (acc[i][j][r] >= tau_r[j] && n < ep.p0) {
+                            if (acc[i][j][r] * WSCALE >= tau_r[j] && n < ep.p0) {
                                 const int pos = atomicAdd(flt.cnt + m, 1);
                                 if (pos < flt.cap) flt.buf_g[(size_t)m * flt.cap + pos] = n;
                             }
@@ -646,6 +713,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
                     }
             }
             const int m = bm * 256 + wm * 128 + j * 16 + fr;
+            mx *= WSCALE;
             if constexpr (FILTER == 1) {
                 if (mx >= tau_r[j] && mx > -INFINITY) {  // (tau_r = +inf for pad queries; -inf maxima = all-pad groups)
                     const int pos = atomicAdd(flt.cnt + m, 1);
@@ -683,7 +751,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
 
 template <int EPI, int XP, int STYLE, int DBG>
 static int launch_gemm256p_kern(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
-    const int lds = P256_RAW + (XP >= 2 ? XP * 8192 : 16384);  // (the epilogue's transpose patches live in the raw-statistics area)
+    const int lds = XP == 1 ? P256_FTAB + 4096 : P256_RAW + (XP >= 2 ? XP * 8192 : 16384);  // (the epilogue's transpose patches live in the raw-statistics area)
     const int T = (M / 256) * (N / 256);
     const int grid = T >= 256 ? 256 : T;
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p_kernel<EPI, XP, STYLE, DBG>), lds));
@@ -717,20 +785,21 @@ static int launch_gemm256p_inst(hipStream_t st, const void* A, const void* W, co
 
 // can this GEMM run on the persistent kernel? (bf16 output epilogues; the folded forms need K = 512 or 768: the raw
 // statistics of a tile must fit beside the staging buffers)
-static inline bool gemm256p_ok(int epi, int M, int N, int K) {
+static inline bool gemm256p_ok(int epi, int M, int N, int K, bool final_stats = false) {
     if (M <= 0 || (M % 256) || N <= 0 || (N % 256) || K < 256 || (K % 256)) return false;
     if ((int64_t)(M / 256) * (N / 256) > 48 * 256 || M / 256 > 0xffff) return false;  // (tile table: 64 entries per workgroup)
     if ((int64_t)M * N * 2 >= (1LL << 31) || (int64_t)M * K * 2 >= (1LL << 31) || (int64_t)N * K * 2 >= (1LL << 31)) return false;  // (32-bit buffer offsets)
-    if (epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16) return K == 512 || K == 768;
+    if (epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16) return final_stats || K == 512 || K == 768;
     return epi == MMISS_EPI_BIAS_BF16 || epi == MMISS_EPI_BIAS_QGELU_BF16;
 }
 
 // M = rows padded to 256 (the output and, in the folded modes, ep.ln_stats must hold M rows); rows >= ep.m_valid are
 // computed but land in row M - 1.
 static int launch_gemm256p(hipStream_t st, int epi, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K) {
-    if (!gemm256p_ok(epi, M, N, K)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256p: epi=%d M=%d N=%d K=%d", epi, M, N, K);
     const bool fold = epi == MMISS_EPI_LNFOLD_BF16 || epi == MMISS_EPI_LNFOLD_QGELU_BF16;
-    if (!ep.out || !ep.bias || (fold && (!ep.ln_stats || !ep.aux || ep.ln_parts * 64 != K)))
+    const bool fin = fold && ep.ln_final != nullptr;
+    if (!gemm256p_ok(epi, M, N, K, fin)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256p: epi=%d M=%d N=%d K=%d", epi, M, N, K);
+    if (!ep.out || !ep.bias || (fold && (!ep.aux || (!fin && (!ep.ln_stats || ep.ln_parts * 64 != K)))))
         MM_FAIL(MMISS_ERR_ARG, "gemm256p: missing operand (fold=%d parts=%d)", (int)fold, ep.ln_parts);
     static const char* names[] = {"", "gemm_bf16_bias_p256", "gemm_bf16_bias_qgelu_p256"};
     const int mv = ep.m_valid < M ? ep.m_valid : M;
@@ -741,16 +810,18 @@ static int launch_gemm256p(hipStream_t st, int epi, const void* A, const void* W
         case MMISS_EPI_BIAS_BF16: return launch_gemm256p_inst<MMISS_EPI_BIAS_BF16, 0>(st, A, W, ep, M, N, K);
         case MMISS_EPI_BIAS_QGELU_BF16: return launch_gemm256p_inst<MMISS_EPI_BIAS_QGELU_BF16, 0>(st, A, W, ep, M, N, K);
         case MMISS_EPI_LNFOLD_BF16:
+            if (fin) return launch_gemm256p_inst<MMISS_EPI_LNFOLD_BF16, 1>(st, A, W, ep, M, N, K);
             return K == 768 ? launch_gemm256p_inst<MMISS_EPI_LNFOLD_BF16, 3>(st, A, W, ep, M, N, K)
                             : launch_gemm256p_inst<MMISS_EPI_LNFOLD_BF16, 2>(st, A, W, ep, M, N, K);
         default:
+            if (fin) return launch_gemm256p_inst<MMISS_EPI_LNFOLD_QGELU_BF16, 1>(st, A, W, ep, M, N, K);
             return K == 768 ? launch_gemm256p_inst<MMISS_EPI_LNFOLD_QGELU_BF16, 3>(st, A, W, ep, M, N, K)
                             : launch_gemm256p_inst<MMISS_EPI_LNFOLD_QGELU_BF16, 2>(st, A, W, ep, M, N, K);
     }
 }
 
-// the strip score GEMM on the staggered loop (same arguments as launch_gemm256_strip; K % 128 == 0)
-template <typename IN>
+// the strip score GEMM on the staggered loop (same arguments as launch_gemm256_strip; K % 128 == 0). W8: W = fp8 rows (1 B / elt)
+template <typename IN, bool W8 = false>
 static int launch_gemm256s(hipStream_t st, const void* A, const void* W, const GemmEpi& ep, int M, int N, int K, int strip,
                            const StripFilter* flt = nullptr) {
     if (M <= 0 || N <= 0 || K < 256 || (M % 256) || (N % 256) || (K % 128) || strip < 1 || strip > 32 ||
@@ -763,19 +834,19 @@ static int launch_gemm256s(hipStream_t st, const void* A, const void* W, const G
             MM_FAIL(MMISS_ERR_ARG, "gemm256s: bad filter");
         const int nwg = (M / 256) * ((nbn - flt->bn_begin + strip - 1) / strip);
         if (rows_mode) {
-            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 2>), G256_LDS));
-            hipLaunchKernelGGL((gemm256s_kernel<IN, 2>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
-                               reinterpret_cast<const IN*>(W), M, N, K, strip, ep, *flt);
+            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 2, W8>), G256_LDS));
+            hipLaunchKernelGGL((gemm256s_kernel<IN, 2, W8>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                               W, M, N, K, strip, ep, *flt);
         } else {
-            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 1>), G256_LDS));
-            hipLaunchKernelGGL((gemm256s_kernel<IN, 1>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
-                               reinterpret_cast<const IN*>(W), M, N, K, strip, ep, *flt);
+            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 1, W8>), G256_LDS));
+            hipLaunchKernelGGL((gemm256s_kernel<IN, 1, W8>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                               W, M, N, K, strip, ep, *flt);
         }
     } else {
-        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 0>), G256_LDS));
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 0, W8>), G256_LDS));
         const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
-        hipLaunchKernelGGL((gemm256s_kernel<IN, 0>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
-                           reinterpret_cast<const IN*>(W), M, N, K, strip, ep, StripFilter{});
+        hipLaunchKernelGGL((gemm256s_kernel<IN, 0, W8>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+                           W, M, N, K, strip, ep, StripFilter{});
     }
     MM_HIP(hipGetLastError());
     return MMISS_OK;

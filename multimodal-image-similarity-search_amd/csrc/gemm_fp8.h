@@ -447,10 +447,101 @@ __global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const void* __rest
     }
 }
 
+// The same arithmetic for a bf16 residual stream with d = NS * 512 (ViT-L/14: 1024), wide accesses (round 4): a lane holds EIGHT
+// consecutive columns per 512-column step (one 16-byte load, one 8-byte store; the first form moves 8 / 4 bytes per lane and
+// re-reads gamma and beta — twice the row's own bytes — for every row), a wave walks four rows with gamma and beta in
+// registers, all four rows' loads issued before the first is used. A 32-column block = 4 lanes: two xor-shuffles.
+// Same statistics, same y, same scales and bytes as layernorm_mxfp8_kernel<true> (the sums run in a different lane order:
+// the last bit of mean / rstd may differ).
+template <int NS>
+__global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, uint8_t* __restrict__ out,
+                                                                     uint8_t* __restrict__ out_scale, int M, int ld_os, float eps) {
+    constexpr int D = NS * 512, RW = 4;
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (r0 >= M) return;
+    float gm[NS][8], bb[NS][8];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int c = i * 512 + lane * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gm[i][e] = g0[e]; gm[i][4 + e] = g1[e]; bb[i][e] = b0[e]; bb[i][4 + e] = b1[e]; }
+    }
+    u32x4 raw[RW][NS];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int r = r0 + j < M ? r0 + j : M - 1;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) raw[j][i] = *reinterpret_cast<const u32x4*>(x + (size_t)r * D + i * 512 + lane * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int r = r0 + j;
+        float v[NS][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                v[i][2 * w] = __uint_as_float(raw[j][i][w] << 16);
+                v[i][2 * w + 1] = __uint_as_float(raw[j][i][w] & 0xFFFF0000u);
+            }
+            s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+        }
+        const float mean = wave_sum(s) * (1.0f / (float)D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            float y[8];
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                y[e] = (v[i][e] - mean) * rstd * gm[i][e] + bb[i][e];
+                amax = fmaxf(amax, fabsf(y[e]));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 1));
+            amax = fmaxf(amax, __shfl_xor(amax, 2));
+            int e8;
+            float inv;
+            mx_scale_of(amax, e8, inv);
+            if (r < M) {
+                const int c = i * 512 + lane * 8;
+                u32x2 pk;
+                pk[0] = pack_fp8x4(y[0] * inv, y[1] * inv, y[2] * inv, y[3] * inv);
+                pk[1] = pack_fp8x4(y[4] * inv, y[5] * inv, y[6] * inv, y[7] * inv);
+                *reinterpret_cast<u32x2*>(out + (size_t)r * D + c) = pk;
+                if ((lane & 3) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
+            }
+        }
+    }
+}
+
 static int launch_layernorm_mxfp8(hipStream_t st, const void* x, bool x_bf16, const float* gamma, const float* beta, uint8_t* out,
                                   uint8_t* out_scale, int M, int d, float eps) {
     if (d > 1024 || (d % 32)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "layernorm_mxfp8: d=%d (need d <= 1024, d %% 32 == 0)", d);
     MM_PROF(x_bf16 ? "layernorm16_mxfp8" : "layernorm_mxfp8", st, 8.0 * M * d, (double)M * d * (x_bf16 ? 3 : 5));
+    if (x_bf16 && (d == 512 || d == 1024) && mmiss_option("ln_mxfp8_wide", 1) != 0) {
+        const int grid = (M + 15) / 16;
+        if (d == 1024)
+            hipLaunchKernelGGL(layernorm16_mxfp8_wide_kernel<2>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
+                               beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
+        else
+            hipLaunchKernelGGL(layernorm16_mxfp8_wide_kernel<1>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
+                               beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
+        MM_HIP(hipGetLastError());
+        return MMISS_OK;
+    }
     if (x_bf16)
         hipLaunchKernelGGL(layernorm_mxfp8_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, gamma, beta, out, out_scale, M, d,
                            mx_scale_row_bytes(d), eps);

@@ -84,7 +84,7 @@ def test_last_layer_pruning_matches_full_computation(tiny):
     assert (1 - _cos(pruned.encode_image(px), enc.encode_image(px))).max() < 1e-4
     assert (1 - _cos(pruned.encode_text(ids), enc.encode_text(ids))).max() < 1e-4
 
-    for mode in ((1, 2) if _lib.has_experiments() else (2,)):  # the pruned tail is the same whatever the LayerNorm mode
+    for mode in (2,):  # the pruned tail is the same whatever the LayerNorm mode
         pruned.set_fuse_ln(mode)
         assert (1 - _cos(pruned.encode_image(px), co.embed_images(px, W, s))).max() < COS_TOL
     assert (1 - _cos(pruned.encode_text(ids), co.embed_texts(ids, W, s))).max() < COS_TOL
@@ -104,7 +104,7 @@ def test_layernorm_modes_agree(tiny):
     from mmiss_amd import _lib
 
     outs = []
-    for mode in ((0, 1, 2) if _lib.has_experiments() else (0, 2)):  # mode 1 (slower) only in EXPERIMENTS builds
+    for mode in (0, 2):  # (mode 1, LayerNorm during operand staging, was removed in round 4)
         e = ClipEncoder(ClipShape.from_any(s), max_batch_image=8, max_batch_text=8)
         e.load_state_dict(W)
         e.set_fuse_ln(mode)

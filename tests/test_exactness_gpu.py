@@ -227,13 +227,13 @@ def test_a_plateau_of_250k_duplicates_ends_in_the_exhaustive_pass(mods, dtype):
     idx.close()
 
 
-@pytest.mark.parametrize("dtype,Q", [("f16", 256), ("f16", 40), ("f32", 40), ("f8", 20)])
+@pytest.mark.parametrize("dtype,Q", [("f16", 256), ("f16", 40), ("f32", 40), ("f8", 20), ("f8", 256)])
 def test_a_clustered_index_where_every_query_is_widened(mods, dtype, Q):
     """BASELINE configs[1] queries each embedding against the index OF those embeddings, and random-weight embeddings sit at
     pairwise cosine ~0.99: the 10th and the 16th best score are closer than the error bound for EVERY query (VERDICT r3
     weak #2). Rows = one common direction + 10 % noise; the queries are index rows (self-match first, distance ~0). Every
     query must be widened by ONE threshold pass (rounds == calls), none may end in the exhaustive pass, and ids + distance
-    bits equal the oracle's. Q = 256 / f16: the score-GEMM threshold pass; the others: the streaming-scan one."""
+    bits equal the oracle's. Q = 256 (f16, f8): the score-GEMM threshold pass; the others: the streaming-scan one."""
     FlatIndex, ro, _ = mods
     N, D, k = 40000, 512, 10
     centre = _unit(_randn(1, D, seed=1300))[0]
@@ -251,9 +251,12 @@ def test_a_clustered_index_where_every_query_is_widened(mods, dtype, Q):
     assert after["widened"] - before["widened"] >= Q * (0.5 if dtype == "f8" else 0.9), (before, after)
     assert after["rounds"] - before["rounds"] == 1 and after["exhaustive"] == before["exhaustive"], (before, after)
     assert after["swept_rows"] - before["swept_rows"] >= Q * k
-    if dtype != "f8":   # (an fp8 row's stored value differs from the query by its quantisation: still first, not at distance 0)
+    if dtype != "f8":
+        # (an fp8 row is stored un-renormalised after its e4m3 rounding — |stored| within 3 % of 1, include/mmiss.h — which is
+        # more than the 1 % between a row and its neighbours here: the index is exact for its STORED rows, the oracle check
+        # below, but a row need not come first for its own unquantised vector)
         assert (dist[:, 0] < 1e-4).all()
-    np.testing.assert_array_equal(lab[:, 0], labels[sel])
+        np.testing.assert_array_equal(lab[:, 0], labels[sel])
     sub = np.arange(0, Q, max(1, Q // 16))
     ol, od, oc = ro.query(q[sub], stored, labels, k)
     np.testing.assert_array_equal(lab[sub], ol)

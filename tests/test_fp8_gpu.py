@@ -86,6 +86,63 @@ def test_layernorm_mxfp8_matches_restatement(env, d):
     assert (np.abs(back - y) <= gmax * 2.0 ** -4 * 1.01 + 1e-6).all()
 
 
+@pytest.mark.parametrize("d", [512, 1024, 768])
+def test_layernorm_mxfp8_from_bf16_rows(env, d):
+    """The large calls keep the residual stream in bf16: LayerNorm -> MXFP8 reads bf16 rows. d = 512 / 1024 run the wide kernel
+    of round 4 (eight columns per lane, four rows per wave, gamma / beta in registers), d = 768 the first form; same bar
+    against the restatement as the f32-input kernel, on the bf16-rounded input."""
+    torch, _lib, lib, fo = env
+    rng = np.random.default_rng(40 + d)
+    M = 131                                                  # not a multiple of the 16 rows a workgroup walks
+    x = (rng.standard_normal((M, d)) * 2 + 0.5).astype(np.float32)
+    x[:, 5] += 40.0
+    xb = torch.from_numpy(x).cuda().to(torch.bfloat16)
+    x = xb.float().cpu().numpy()
+    gam = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    bet = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    gd, bd = torch.from_numpy(gam).cuda(), torch.from_numpy(bet).cuda()
+    out = torch.zeros((M + 5, d), dtype=torch.uint8, device="cuda")
+    osc = torch.zeros((M + 5, fo.scale_row_bytes(d)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.mmiss_dbg_layernorm16_mxfp8(0, None, xb.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+                                               osc.data_ptr(), M, d, 1e-5))
+    torch.cuda.synchronize()
+    assert int(out[M:].sum()) == 0 and int(osc[M:].sum()) == 0          # nothing behind row M - 1 is touched
+    mu = x.mean(1, keepdims=True, dtype=np.float64)
+    var = ((x - mu) ** 2).mean(1, keepdims=True, dtype=np.float64)
+    y = (((x - mu) / np.sqrt(var + 1e-5)) * gam + bet).astype(np.float32)
+    q, e = fo.mx_quantize(y, 32)
+    got_e = fo.unpermute_scales(osc[:M].cpu().numpy(), d)
+    got_q = out[:M].cpu().numpy()
+    assert (got_e == e).mean() > 0.999
+    same = got_e.repeat(32, axis=1) == e.repeat(32, axis=1)
+    assert ((got_q == q) | ~same).mean() > 0.998
+    back = fo.mx_dequantize(got_q, got_e)
+    gmax = np.abs(y).reshape(M, -1, 32).max(axis=2).repeat(32, axis=1)
+    assert (np.abs(back - y) <= gmax * 2.0 ** -4 * 1.01 + 1e-6).all()
+
+
+@pytest.mark.parametrize("B,T,H", [(3, 257, 16), (2, 200, 4)])
+def test_attention_with_mxfp8_output(env, B, T, H):
+    """The fp8 vision tower's attention writes its output as MXFP8 (the out-projection's A operand on the fp8 GEMM): the
+    dequantised bytes must equal the bf16-output kernel's rows up to the e4m3 rounding of a block — 2^-4 of the block's
+    largest magnitude — and the bf16 kernel itself is held against torch in tests/test_kernels_gpu.py."""
+    torch, _lib, lib, fo = env
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
+    qkv = torch.randn(B * T, 3 * H * 64, device="cuda", generator=g).to(torch.bfloat16)
+    ctx = torch.zeros(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mmiss_dbg_attention(0, None, qkv.data_ptr(), ctx.data_ptr(), B, T, H, 0))
+    c8 = torch.zeros(B * T, H * 64, device="cuda", dtype=torch.uint8)
+    cs = torch.zeros(B * T, fo.scale_row_bytes(H * 64), device="cuda", dtype=torch.uint8)
+    _lib.check(lib.mmiss_dbg_attention_mx(0, None, qkv.data_ptr(), c8.data_ptr(), cs.data_ptr(), B, T, H))
+    torch.cuda.synchronize()
+    ref = ctx.float().cpu().numpy()
+    back = fo.mx_dequantize(c8.cpu().numpy(), fo.unpermute_scales(cs.cpu().numpy(), H * 64))
+    gmax = np.abs(ref).reshape(B * T, -1, 32).max(axis=2).repeat(32, axis=1)
+    # (the bf16 kernel rounds its f32 result to bf16, the MXFP8 one to e4m3: 2^-4 of the block maximum + the bf16 rounding)
+    assert (np.abs(back - ref) <= gmax * (2.0 ** -4 * 1.01 + 2.0 ** -8) + 1e-6).all()
+    assert np.isfinite(back).all()
+
+
 @pytest.mark.parametrize("epi,bm,M,N,K", [(0, 128, 256, 256, 512), (0, 160, 320, 384, 768), (2, 192, 384, 128, 4096),
                                           (1, 128, 128, 512, 1024), (1, 160, 480, 256, 768), (2, 128, 128, 256, 128)])
 def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
@@ -311,7 +368,25 @@ def test_longclip_l14_full_depth_vision_bf16_and_fp8(env):
     print("L/14 24 layers: 1-cos vs oracle  bs 8: bf16 %.2e fp8 %.2e   bs 128 (first 8): bf16 %.2e fp8 %.2e"
           % (d16.max(), d8.max(), d16_128.max(), d8_128.max()))
     assert kern.get("gemm_fp8_bias", 0) == 24 and kern.get("gemm_fp8_bias_resid", 0) == 23, kern
-    assert kern128.get("gemm_fp8_bias", 0) == 24 and kern128.get("gemm_fp8_bias_resid16", 0) == 23, kern128
+    # round 4: at the config's batch the attention output leaves its kernel as MXFP8 and the out-projection is an fp8 GEMM
+    # too (23 layers; the pruned last layer keeps the bf16 form): 23 FC2 + 23 out-projections on gemm_fp8_bias_resid16
+    assert kern128.get("gemm_fp8_bias", 0) == 24 and kern128.get("gemm_fp8_bias_resid16", 0) == 46, kern128
+    assert kern128.get("attention_mx", 0) == 23 and kern128.get("attention", 0) == 1, kern128
     assert d16.max() < COS_TOL and d16_128.max() < COS_TOL, (d16, d16_128)
     assert d8.max() < COS_TOL and d8_128.max() < COS_TOL, (d8, d8_128)
     assert np.isfinite(out8_128).all() and np.abs(np.linalg.norm(out8_128, axis=1) - 1).max() < 1e-5
+    # ... and with the out-projection back on the bf16 GEMM (option fp8_outproj = 0, the round-3 form): measured side by side
+    from mmiss_amd import _lib as _l
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=128, max_batch_text=2)
+    enc.load_state_dict(W)
+    enc.set_precision("fp8")
+    _l.set_option("fp8_outproj", 0)
+    try:
+        (out8_b, kern_b) = _with_kernels(lambda: enc.encode_image(px))
+    finally:
+        _l.set_option("fp8_outproj", 1)
+        enc.close()
+    d8_b = 1 - _cos(out8_b[:8], ref)
+    print("   out-projection bf16 (fp8_outproj = 0): fp8 bs 128 (first 8) %.2e" % d8_b.max())
+    assert kern_b.get("gemm_fp8_bias_resid16", 0) == 23 and kern_b.get("attention_mx", 0) == 0, kern_b
+    assert d8_b.max() < COS_TOL

@@ -45,6 +45,48 @@ def test_query_matches_oracle(mods, dtype, N, D):
         _check(idx, ro, stored, labels, q, k)
 
 
+@pytest.mark.parametrize("N,D,Q", [(20011, 512, 200), (70001, 768, 300), (40000, 256, 1024)])
+def test_fp8_rows_on_the_score_gemm(mods, N, D, Q):
+    """Round 4: from two 128-query tiles on, an fp8 index takes the strip score GEMM too (its e4m3 codes widened to f16 in the
+    kernel's operand load; 64-byte rows in LDS, one ds_read_b64 per fragment) instead of re-streaming the index once per 64
+    queries. ids + distance bits against the oracle's restatement of the fp8 rounding; the same queries through the
+    streaming scan (option score_f8_gemm = 0) must return the same bits; 40 000 x 256 x 1024 = the threshold-filtered form."""
+    from mmiss_amd import _lib
+
+    FlatIndex, _, _, ro = mods
+    c = _corpus(N, D, seed=N + D + 1)
+    labels = np.arange(N, dtype=np.int64) * 3 + 5
+    idx = FlatIndex(D, "f8")
+    idx.add(c, labels)
+    stored = ro.normalize_rows(c, "f8")
+    q = _corpus(Q, D, seed=2000 + Q)
+    _lib.prof_filter(None, 1); _lib.prof_reset(); _lib.prof_enable(True)
+    if Q == 1024:
+        _lib.set_option("score_filter", 2)
+    try:
+        lab, dist, cnt = idx.query(q, 10)
+    finally:
+        _lib.set_option("score_filter", 1)
+        _lib.prof_enable(False)
+    kern = {p["kernel"] for p in _lib.prof_read()}
+    assert "score_gemm_f8" in kern and "scan_topk_f8" not in kern, kern
+    if Q == 1024:
+        assert "score_gemm_f8_sample" in kern, kern
+    sub = np.arange(0, Q, max(1, Q // 24))
+    ol, od, oc = ro.query(q[sub], stored, labels, 10)
+    np.testing.assert_array_equal(lab[sub], ol)
+    np.testing.assert_array_equal(dist[sub].view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(cnt[sub], oc)
+    _lib.set_option("score_f8_gemm", 0)
+    try:
+        l2, d2, _ = idx.query(q, 10)
+    finally:
+        _lib.set_option("score_f8_gemm", 1)
+    np.testing.assert_array_equal(l2, lab)
+    np.testing.assert_array_equal(d2.view(np.uint32), dist.view(np.uint32))
+    idx.close()
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16", "f8"])
 def test_large_k_paging_and_k_beyond_count(mods, dtype):
     FlatIndex, _, _, ro = mods

@@ -107,77 +107,6 @@ def test_gemm_256_tile_pipeline(env, M, N, K):
     assert torch.equal(o128, o256)
 
 
-@pytest.mark.parametrize("bm,M,N,K", [(128, 128, 128, 32), (128, 256, 256, 64), (160, 320, 256, 96), (192, 384, 128, 128),
-                                      (160, 1600, 768, 768), (128, 256, 384, 160), (192, 768, 256, 3072)])
-def test_gemm_ring_pipeline(env, bm, M, N, K):
-    """The 4-slot ring variant (32-deep stages, counted vmcnt): stage counts 1..96 cover prologue, steady state and
-    tail; results must be bit-identical to the drain-per-tile kernel (same per-element k order)."""
-    torch, _lib, lib = env
-    if not _lib.has_experiments():
-        pytest.skip("measured-slower variant: only in `make EXPERIMENTS=1` builds")
-    g = torch.Generator(device="cuda").manual_seed(bm + M + N + K)
-    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
-    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
-    bias = torch.randn(N, device="cuda", generator=g)
-    ref = A.float() @ W.float().T
-    for rep in range(4):
-        out = torch.full((M, N), float("nan"), device="cuda")
-        _gemm(env, _lib.EPI_F32, A, W, out, bm=1000 + bm)
-        assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item()), rep
-    if K % 64 == 0:
-        base = torch.zeros(M, N, device="cuda")
-        _lib.set_option("gemm_skinny", 0)  # small M would otherwise take the weight-streaming kernel
-        _lib.set_option("gemm_splitk", 0)
-        try:
-            _gemm(env, _lib.EPI_F32, A, W, base, bm=bm)
-        finally:
-            _lib.set_option("gemm_skinny", 1)
-            _lib.set_option("gemm_splitk", 1)
-        assert torch.equal(out, base)
-    x0 = torch.randn(M, N, device="cuda", generator=g)
-    x = x0.clone()
-    _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias, bm=1000 + bm)
-    assert torch.allclose(x, x0 + ref + bias, rtol=1e-5, atol=2e-4)
-    ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-    _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, ob, bias=bias, bm=1000 + bm)
-    r2 = ref + bias
-    assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
-
-
-@pytest.mark.parametrize("bm,M,N,K", [(128, 256, 256, 64), (160, 320, 512, 192), (192, 768, 768, 768), (160, 1600, 2304, 768)])
-def test_gemm_wide_tile(env, bm, M, N, K):
-    """The BM x 256 tile with 8 waves (variant 2000 + BM): same arithmetic order per element as the BM x 128 tile, so
-    bit-identical to it, and all epilogues against the fp32 restatement."""
-    torch, _lib, lib = env
-    if not _lib.has_experiments():
-        pytest.skip("measured-slower variant: only in `make EXPERIMENTS=1` builds")
-    g = torch.Generator(device="cuda").manual_seed(bm + M + N + K)
-    A = _bf16(torch.randn(M, K, device="cuda", generator=g))
-    W = _bf16(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
-    bias = torch.randn(N, device="cuda", generator=g)
-    ref = A.float() @ W.float().T
-    out = torch.full((M, N), float("nan"), device="cuda")
-    _gemm(env, _lib.EPI_F32, A, W, out, bm=2000 + bm)
-    assert (out - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
-    base = torch.zeros(M, N, device="cuda")
-    _lib.set_option("gemm_skinny", 0)
-    _lib.set_option("gemm_splitk", 0)
-    try:
-        _gemm(env, _lib.EPI_F32, A, W, base, bm=bm)
-    finally:
-        _lib.set_option("gemm_skinny", 1)
-        _lib.set_option("gemm_splitk", 1)
-    assert torch.equal(out, base)
-    ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-    _gemm(env, _lib.EPI_BIAS_QGELU_BF16, A, W, ob, bias=bias, bm=2000 + bm)
-    r2 = ref + bias
-    assert torch.allclose(ob.float(), r2 * torch.sigmoid(1.702 * r2), rtol=2 ** -7, atol=2e-3)
-    x0 = torch.randn(M, N, device="cuda", generator=g)
-    x = x0.clone()
-    _gemm(env, _lib.EPI_BIAS_RESID_F32, A, W, x, bias=bias, bm=2000 + bm)
-    assert torch.allclose(x, x0 + ref + bias, rtol=1e-5, atol=2e-4)
-
-
 @pytest.mark.parametrize("M,N,K", [(384, 768, 3072), (1280, 768, 3072), (256, 256, 1536), (640, 1024, 4096)])
 def test_gemm_split_k(env, M, N, K):
     """Few tiles and a long K: the K loop is cut into slices run by different workgroups (partials in scratch, summed
