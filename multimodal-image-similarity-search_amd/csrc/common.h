@@ -113,6 +113,25 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// max WITHOUT the canonicalising `v_max x, x` that fmaxf() emits in front of every use of a value the compiler cannot prove
+// quiet (an MFMA result, a loaded float): maxnum must quiet a signalling NaN. Where the operands are never one — scores,
+// magnitudes — these save one vector instruction per operand (round 4: 12 of ~60 per key-pair step of the long attention).
+// CAUTION (guide 5.7 item 2): hipcc pads the MFMA-result -> VALU-read hazard only for consumers it models; an `asm` statement is
+// opaque to its hazard recogniser. Values that may come STRAIGHT out of an MFMA must pass mm_mfma_settle() (an s_nop covering the
+// 8-pass XDL write -> VALU read window) before they enter mm_max2 / mm_max3; without it the maxima read stale accumulator
+// registers now and then (seen as run-to-run differences of the online softmax's offsets).
+#define mm_mfma_settle(...) asm volatile("s_nop 11" : __VA_ARGS__)
+__device__ __forceinline__ float mm_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float mm_max2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -486,18 +486,9 @@ __device__ __forceinline__ void attention_onepass_tile(const char* sK, const cha
     }
 }
 
-// long sequences: 8 waves share one staged K/V image. (One wave per pair of query tiles — 9 waves for the 17 tiles of
-// ViT-L/14, so that no wave walks a third pass for the one-row 17th tile — measured SLOWER: 125 vs 101 us per layer.)
-#define ATT_THREADS(NKP) ((NKP) > 4 ? 512 : 256)
-// MXOUT (long-sequence form only; the fp8 vision tower's out-projection on the block-scaled fp8 GEMM, round 4): INSTEAD of
-// the bf16 rows the kernel writes the attention output as MXFP8 — e4m3 bytes ctx8 [B*T, H*64] and one E8M0 scale per
-// (row, 32 columns) in the permuted layout of gemm_fp8.h (ctxs, ld_s bytes per row). A (query, head) holds two 32-column
-// blocks (output rows dt 0,1 / 2,3 of O^T); a lane has 8 values of each, the block maximum is one lane-local maximum and two
-// xor-shuffles over the four lane groups.
-template <int NKP, bool CAUSAL, bool MXOUT = false>
-__global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
-                                                        int T, int H, uint8_t* __restrict__ ctx8 = nullptr,
-                                                        uint8_t* __restrict__ ctxs = nullptr, int ld_s = 0) {
+template <int NKP, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx, int T, int H) {
+    static_assert(NKP <= 4, "sequences over 128 keys: attention_long_kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKP * 32;
     char* sK = smem;             // [TP][128 B], 16-B chunks XOR-swizzled by (row & 7)
@@ -507,7 +498,7 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
     const int dmodel = H * 64, ld = 3 * dmodel;
     const uint16_t* base = qkv + (size_t)b * T * ld + h * 64;
 
-    constexpr int NW = ATT_THREADS(NKP) / 64;
+    constexpr int NW = 4;
     const int fr = lane & 15, fg = lane >> 4;
     // The Q fragments of this wave's first query tile are fetched BEFORE the K/V image is staged: their global latency then
     // overlaps the staging loads instead of following the barrier (the kernel is a chain of dependent latencies, not
@@ -549,30 +540,99 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                 qf[s] = __builtin_bit_cast(bf16x8, raw);
             }
         }
-        if constexpr (NKP > 4) {
-            // ---- long sequences (ViT-L/14: 257 keys, LongCLIP text: 248): holding all 2*NKP score tiles costs 288 VGPRs
-            // (one wave per SIMD). Two passes instead - pass 1 only finds the row maxima, pass 2 recomputes each score
-            // tile, exponentiates it and feeds it straight to the PV MFMA - keep 2 tiles live (< 64 VGPRs); the extra
-            // QK^T MFMAs are cheap next to the occupancy. Same maxima, same exp arguments, same summation order as the
-            // one-pass form: bit-identical output.
-            // This form is bound by VALU issue, not by the matrix cores (PMC at T = 257: instruction issue busy 84 % of the
-            // kernel, MFMA 22 %): so the per-score vector work is kept minimal —
-            //  * raw scores (no scale): max and exp take the 1/8 scale and log2(e) in ONE fma: exp(s/8 - m/8) = exp2(s*c - m*c);
-            //  * key-validity / causal masks only on the tiles that can contain an invalid key (wave-uniform test);
-            //  * causal: key tiles entirely above the diagonal are skipped, not computed and masked.
-            const float c_exp = 0.125f * 1.4426950408889634f;
+        attention_onepass_tile<NKP, CAUSAL>(sK, sV, qf, q, T, fr, fg, ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4, long sequences (ViT-L/14: 257 keys, LongCLIP text: 248): 8 waves share one staged K/V image (78 KB for 288 padded keys:
+// two workgroups per CU). Holding all score tiles of a query tile costs 288 VGPRs, so the scores are walked 32 keys at a time.
+// Round 4 (measured on the round-3 form, 128 images x 16 heads, 97-107 us per layer: its two phases ADD — 27 us of K/V
+// staging with nothing computing, 78 us of query tiles with nothing loading — and the query tiles are bound by vector +
+// matrix issue together, which the second pass over Q K^T that only found the row maxima fed for nothing):
+//   * ONE pass, online softmax: the running offset m of a query is raised — and the output tile and the denominator rescaled
+//     by exp2((m_old - m_new) c) — only when a new score exceeds it by more than 8 / c (the probabilities then stay below 2^8:
+//     bf16 keeps its 8 bits at any magnitude, the sums are f32). After the first key tiles that is rare; the branch is
+//     wave-uniform (any lane). The four lanes that hold one query's keys agree on the maximum through two half-wave /
+//     16-lane-row swaps in the vector unit (v_permlane32_swap, v_permlane16_swap), no LDS round trip.
+//   * the softmax denominator comes from the matrix cores: a row tile of ones beside V^T sums the bf16 probabilities — the
+//     ones the PV product uses — into every register of lacc (no vector add per score, no shuffle at the end).
+//   (NOT kept: a workgroup walking several (item, head) pairs with the next pair's K/V rows in flight in registers — 40 more
+//   VGPRs at the 128 that four waves per SIMD allow: 90-95 us against 83 without, the query tiles alone 74 against 64.)
+//   * raw scores: the 1/8 scale and log2(e) ride in the ONE fma in front of v_exp_f32; key-validity / causal masks only on
+//     boundary tiles; causal key tiles above the diagonal skipped; every LDS address a per-lane constant + a tile multiple.
+// MXOUT (the fp8 vision tower's out-projection on the block-scaled fp8 GEMM): INSTEAD of the bf16 rows the kernel writes the
+// output as MXFP8 — e4m3 bytes ctx8 [B*T, H*64] and one E8M0 scale per (row, 32 columns) in the permuted layout of
+// gemm_fp8.h (ctxs, ld_s bytes per row). A (query, head) holds two 32-column blocks (output rows dt 0,1 / 2,3 of O^T); a lane
+// has 8 values of each, the block maximum is one lane-local maximum and two xor-shuffles over the four lane groups.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float att_max_over_lane_groups(float v) {   // max over lanes l, l ^ 16, l ^ 32, l ^ 48
+    uint32_t u = __float_as_uint(v);
+    auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = mm_max2(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+    u = __float_as_uint(v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return mm_max2(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+}
+
+template <int NKP, bool CAUSAL, bool MXOUT>
+__global__ __launch_bounds__(512) void attention_long_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx, int T,
+                                                             int H, uint8_t* __restrict__ ctx8, uint8_t* __restrict__ ctxs, int ld_s,
+                                                             int dbg) {
+    static_assert(NKP > 4 && NKP <= 9, "129..288 keys");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TP = NKP * 32;
+    constexpr int NW = 8;
+    char* sK = smem;             // [TP][128 B], 16-B chunks XOR-swizzled by (row & 7)
+    char* sV = smem + TP * 128;  // [TP][144 B] row-major
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dmodel = H * 64, ld = 3 * dmodel;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nqt = (dbg & 2) ? 0 : (T + 15) >> 4;   // (dbg: timing ablations, option att_dbg — 1 = no K/V loads, 2 = no query tiles)
+    const float c_exp = 0.125f * 1.4426950408889634f;
+    const float thr_raw = 8.0f / c_exp;              // deferred rescale: the offset may lag the maximum by 8 binary orders
+    // per-lane constants of the LDS addresses (krow & 7 = fr & 7: a key tile starts at a multiple of 16 rows)
+    const char* kbase0 = sK + fr * 128 + ((fg ^ (fr & 7)) << 4);
+    const char* kbase1 = sK + fr * 128 + (((4 + fg) ^ (fr & 7)) << 4);
+    const int tq = fr >> 2, tp = fr & 3;             // tr-read address role inside the 16-lane group
+    const char* vbase = sV + (4 * fg + tq) * ATT_VSTRIDE + 8 * tp;   // + ks * 32 rows + dt * 32 bytes (+ 16 rows)
+    u32x4 ones_raw = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    asm volatile("" : "+v"(ones_raw));   // (opaque: kept in four registers instead of three v_mov per key-pair step)
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_raw);
+
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+    const uint16_t* base = qkv + (size_t)b * T * ld + h * 64;
+    for (int idx = tid; idx < TP * 8; idx += NW * 64) {
+        const int row = idx >> 3, c = idx & 7;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (row < T && !(dbg & 1)) {
+            kv = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + dmodel + c * 8);
+            vv = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + 2 * dmodel + c * 8);
+        }
+        *reinterpret_cast<u32x4*>(sK + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
+        *reinterpret_cast<u32x4*>(sV + row * ATT_VSTRIDE + (c << 4)) = vv;
+    }
+    __syncthreads();
+    {
+        // gridDim.y workgroups share one (b, h): small batches split the query tiles so that the grid still fills the chip
+        for (int qt = wave + NW * blockIdx.y; qt < nqt; qt += NW * gridDim.y) {
+            const int q = qt * 16 + fr;
+            bf16x8 qf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4 raw = {0u, 0u, 0u, 0u};
+                if (q < T) raw = *reinterpret_cast<const u32x4*>(base + (size_t)q * ld + s * 32 + fg * 8);
+                qf[s] = __builtin_bit_cast(bf16x8, raw);
+            }
             const int kt_end = CAUSAL ? (qt + 1 < nqt ? qt + 1 : nqt) : nqt;  // key tiles this query tile needs (nqt = ceil(T/16))
             // tiles [0, kt_clean) hold only valid keys for every query of the tile: no mask
             const int kt_clean = CAUSAL ? (qt < (T >> 4) ? qt : (T >> 4)) : (T >> 4);
             auto score_tile = [&](int kt) -> f32x4 {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                const int krow = kt * 16 + fr;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int chunk = 4 * s + fg;
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + ((chunk ^ (krow & 7)) << 4));
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
-                }
+                const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kbase0 + kt * 2048);
+                const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kbase1 + kt * 2048);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[0], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[1], a, 0, 0, 0);
                 if (kt >= kt_clean) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -583,37 +643,40 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                 }
                 return a;
             };
-            float mx = -INFINITY;
-#pragma unroll 2
-            for (int kt = 0; kt < kt_end; ++kt) {
-                const f32x4 a = score_tile(kt);
-                mx = fmaxf(fmaxf(mx, fmaxf(a[0], a[1])), fmaxf(a[2], a[3]));
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mxc = mx * c_exp;
-            // The softmax denominator comes from the matrix cores too (round 4): a fifth "row tile" of V^T made of ones —
-            // lacc = 1 * P^T — sums the bf16 P of every key of this lane's query into every register of lacc, with no vector
-            // add per score and no shuffle across the lane groups (the kernel is bound by vector issue, the matrix pipe is
-            // a quarter busy). It is the sum of the ROUNDED probabilities, the ones the PV product uses: the weights of the
-            // output row sum to one exactly.
-            const u32x4 ones_raw = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-            const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_raw);
+            float m = -INFINITY;   // this query's offset (raw score units): exp2((s - m) c) is what enters P
             f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
             f32x4 oacc[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int tq = fr >> 2, tp = fr & 3;
-            const int ks_end = (kt_end + 1) >> 1;
-#pragma unroll 1
-            for (int ks = 0; ks < ks_end; ++ks) {
+            // one step = two key tiles (the 32 keys of one PV MFMA); an odd last tile is a step of its own (second tile -inf)
+            auto step = [&](int ks, auto pair_tag) {
+                constexpr bool PAIR = decltype(pair_tag)::value;
                 f32x4 p0 = score_tile(2 * ks), p1;
-                if (2 * ks + 1 < kt_end) p1 = score_tile(2 * ks + 1);
+                if constexpr (PAIR) p1 = score_tile(2 * ks + 1);
                 else p1 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                if constexpr (PAIR) mm_mfma_settle("+v"(p0), "+v"(p1));   // (the asm maxima below read MFMA results: common.h)
+                else mm_mfma_settle("+v"(p0));
+                float lm = mm_max3(p0[0], p0[1], p0[2]);
+                if constexpr (PAIR) lm = mm_max3(mm_max3(lm, p0[3], p1[0]), p1[1], mm_max2(p1[2], p1[3]));
+                else lm = mm_max2(lm, p0[3]);
+                lm = att_max_over_lane_groups(lm);   // the same value in the four lanes of a query
+                if (__any(lm > m + thr_raw)) {       // (m = -inf at the first step: taken, alpha = 0 on zeros)
+                    const float mn = (lm > m + thr_raw) ? lm : m;
+                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c_exp);   // 1 where the offset stays; exp2(-inf) = 0
+                    m = mn;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p0[r], c_exp, -mxc));
+                    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p1[r], c_exp, -mxc));
+                        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lacc[r] *= alpha;
+                }
+                const float mc = m * c_exp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p0[r], c_exp, -mc));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p1[r], c_exp, -mc));
+                // B fragment of O^T = V^T P^T: element j < 4 = key 32 ks + 4 fg + j, j >= 4 = key 32 ks + 16 + 4 fg + (j - 4)
                 u32x4 praw;
                 praw[0] = pack_bf16x2(p0[0], p0[1]);
                 praw[1] = pack_bf16x2(p0[2], p0[3]);
@@ -621,9 +684,10 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                 praw[3] = pack_bf16x2(p1[2], p1[3]);
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, praw);
                 lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, lacc, 0, 0, 0);
+                const char* vks = vbase + ks * (32 * ATT_VSTRIDE);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const char* a0 = sV + (32 * ks + 4 * fg + tq) * ATT_VSTRIDE + (dt * 16 + 4 * tp) * 2;
+                    const char* a0 = vks + dt * 32;
                     const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
                         (__attribute__((address_space(3))) bf16x4*)(a0));
                     const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
@@ -633,7 +697,11 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                     vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
                     oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);
                 }
-            }
+            };
+            const int npairs = kt_end >> 1;
+#pragma unroll 1
+            for (int ks = 0; ks < npairs; ++ks) step(ks, std::true_type{});
+            if (kt_end & 1) step(npairs, std::false_type{});
             const float inv = 1.0f / lacc[0];
             if constexpr (MXOUT) {
                 const size_t row = (size_t)b * T + (q < T ? q : 0);
@@ -648,8 +716,7 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                             o[i][r] = oacc[2 * blk + i][r] * inv;
                             amax = fmaxf(amax, fabsf(o[i][r]));
                         }
-                    amax = fmaxf(amax, __shfl_xor(amax, 16));
-                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    amax = att_max_over_lane_groups(amax);
                     int e8;
                     float sinv;
                     mx_scale_of(amax, e8, sinv);
@@ -661,9 +728,7 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                         if (fg == 0) ctxs[row * ld_s + mx_scale_offset(2 * h + blk)] = (uint8_t)e8;
                     }
                 }
-                continue;
-            }
-            if (q < T) {
+            } else if (q < T) {
                 uint16_t* orow = ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -673,9 +738,7 @@ __global__ __launch_bounds__(ATT_THREADS(NKP)) void attention_kernel(const uint1
                     *reinterpret_cast<u32x2*>(orow + dt * 16) = pk;
                 }
             }
-            continue;
         }
-        attention_onepass_tile<NKP, CAUSAL>(sK, sV, qf, q, T, fr, fg, ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg);
     }
 }
 
@@ -834,53 +897,58 @@ static int launch_im2col(hipStream_t st, const void* pixels, bool src_u8, void* 
     return MMISS_OK;
 }
 
-// the long-sequence form writing MXFP8 (attention_kernel<NKP, false, true>): non-causal only (the vision tower), 129..288 keys
-template <int NKP>
-static int launch_attention_mx_nkp(hipStream_t st, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
+template <int NKP, bool CAUSAL, bool MXOUT>
+static int launch_attention_long_t(hipStream_t st, const void* qkv, void* ctx, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T,
+                                   int H) {
     const int lds = NKP * 32 * (128 + ATT_VSTRIDE);
-    constexpr int NW = ATT_THREADS(NKP) / 64;
-    const int rounds = ((T + 15) / 16 + NW - 1) / NW;
-    int qs = 256 / (B * H);
+    const int items = B * H;
+    // query-tile splits per (b, h): 1 once B*H covers the 256 CUs (one ViT-L/14 image: 16 heads x 17 query tiles ->
+    // 3 splits = 48 workgroups instead of 16 walking 3 rounds each)
+    const int rounds = ((T + 15) / 16 + 7) / 8;
+    int qs = 256 / items;
     qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<NKP, false, true>), lds));
-    hipLaunchKernelGGL((attention_kernel<NKP, false, true>), dim3(B * H, qs), dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
-                       (uint16_t*)nullptr, T, H, ctx8, ctxs, ld_s);
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_long_kernel<NKP, CAUSAL, MXOUT>), lds));
+    hipLaunchKernelGGL((attention_long_kernel<NKP, CAUSAL, MXOUT>), dim3(items, qs), dim3(512), lds, st, (const uint16_t*)qkv,
+                       (uint16_t*)ctx, T, H, ctx8, ctxs, ld_s, mmiss_option("att_dbg", 0));
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }
+
+template <bool CAUSAL, bool MXOUT>
+static int launch_attention_long(hipStream_t st, const void* qkv, void* ctx, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
+    switch ((T + 31) / 32) {
+        case 5: return launch_attention_long_t<5, CAUSAL, MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, T, H);
+        case 6: return launch_attention_long_t<6, CAUSAL, MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, T, H);
+        case 7: return launch_attention_long_t<7, CAUSAL, MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, T, H);
+        case 8: return launch_attention_long_t<8, CAUSAL, MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, T, H);
+        default: return launch_attention_long_t<9, CAUSAL, MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, T, H);
+    }
+}
+
+// the long-sequence form writing MXFP8: non-causal only (the vision tower), 129..288 keys
 static bool attention_mx_ok(int T, int H) { return T > 128 && T <= 288 && H > 0; }
 static int launch_attention_mx(hipStream_t st, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
     if (B <= 0) return MMISS_OK;
     if (!attention_mx_ok(T, H) || !ctx8 || !ctxs || ld_s < mx_scale_row_bytes(H * 64))
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "attention (MXFP8 output): T=%d (129..288), H=%d", T, H);
     MM_PROF("attention_mx", st, 4.0 * B * H * (double)T * T * 64, (double)B * T * H * 64 * (2 * 3 + 1));
-    switch ((T + 31) / 32) {
-        case 5: return launch_attention_mx_nkp<5>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
-        case 6: return launch_attention_mx_nkp<6>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
-        case 7: return launch_attention_mx_nkp<7>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
-        case 8: return launch_attention_mx_nkp<8>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
-        default: return launch_attention_mx_nkp<9>(st, qkv, ctx8, ctxs, ld_s, B, T, H);
-    }
+    return launch_attention_long<false, true>(st, qkv, nullptr, ctx8, ctxs, ld_s, B, T, H);
 }
 
 template <int NKP>
 static int launch_attention_nkp(hipStream_t st, const void* qkv, void* ctx, int B, int T, int H, bool causal) {
     const int lds = NKP * 32 * (128 + ATT_VSTRIDE);
-    // query-tile splits per (b, h): 1 once B*H covers the 256 CUs (one ViT-L/14 image: 16 heads x 17 query tiles ->
-    // 5 splits = 80 workgroups instead of 16 walking 5 tiles each)
-    constexpr int NW = ATT_THREADS(NKP) / 64;
-    const int rounds = ((T + 15) / 16 + NW - 1) / NW;
+    // query-tile splits per (b, h): 1 once B*H covers the 256 CUs
+    const int rounds = ((T + 15) / 16 + 3) / 4;
     int qs = 256 / (B * H);
     qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
     const dim3 grid(B * H, qs);
     if (causal) {
         MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<NKP, true>), lds));
-        hipLaunchKernelGGL((attention_kernel<NKP, true>), grid, dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
-                           (uint16_t*)ctx, T, H);
+        hipLaunchKernelGGL((attention_kernel<NKP, true>), grid, dim3(256), lds, st, (const uint16_t*)qkv, (uint16_t*)ctx, T, H);
     } else {
         MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<NKP, false>), lds));
-        hipLaunchKernelGGL((attention_kernel<NKP, false>), grid, dim3(ATT_THREADS(NKP)), lds, st, (const uint16_t*)qkv,
-                           (uint16_t*)ctx, T, H);
+        hipLaunchKernelGGL((attention_kernel<NKP, false>), grid, dim3(256), lds, st, (const uint16_t*)qkv, (uint16_t*)ctx, T, H);
     }
     MM_HIP(hipGetLastError());
     return MMISS_OK;
@@ -942,10 +1010,7 @@ static int launch_attention(hipStream_t st, const void* qkv, void* ctx, int B, i
         case 2: return launch_attention_nkp<2>(st, qkv, ctx, B, T, H, causal);
         case 3: return launch_attention_nkp<3>(st, qkv, ctx, B, T, H, causal);
         case 4: return launch_attention_nkp<4>(st, qkv, ctx, B, T, H, causal);
-        case 5: return launch_attention_nkp<5>(st, qkv, ctx, B, T, H, causal);
-        case 6: return launch_attention_nkp<6>(st, qkv, ctx, B, T, H, causal);
-        case 7: return launch_attention_nkp<7>(st, qkv, ctx, B, T, H, causal);
-        case 8: return launch_attention_nkp<8>(st, qkv, ctx, B, T, H, causal);
-        default: return launch_attention_nkp<9>(st, qkv, ctx, B, T, H, causal);
     }
+    return causal ? launch_attention_long<true, false>(st, qkv, ctx, nullptr, nullptr, 0, B, T, H)
+                  : launch_attention_long<false, false>(st, qkv, ctx, nullptr, nullptr, 0, B, T, H);
 }

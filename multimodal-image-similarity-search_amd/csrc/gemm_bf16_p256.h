@@ -155,12 +155,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                 if constexpr (((PCS) & 2) != 0) P256_BLDS4(srdA, a_vo, so_ + row8, dst_ + 1024);            \
             }                                                                                               \
         } else if constexpr (W8) {                                                                          \
-            /* fp8 index rows: a slot is 128 rows x 64 bytes = ONE 16-row piece per wave; the second operation the */ \
-            /* counted waits expect is a 4-byte-per-lane filler into the slot's unused upper half */          \
+            /* fp8 index rows: a slot is 128 rows x 64 bytes = ONE 16-row piece per wave (the counted waits know: P256_WAIT) */ \
             const int so_ = (oW) + ((which) & 1) * 4 * w_row8;                                              \
             char* dst8_ = smem + P256_SLOT(which, b) + wave * 1024;                                         \
             if constexpr (((PCS) & 1) != 0) P256_BLDS(srdW, w_vo, so_, dst8_);                              \
-            if constexpr (((PCS) & 2) != 0) P256_BLDS4(srdW, w_vo, so_, smem + P256_SLOT(which, b) + 8192 + wave * 256); \
         } else {                                                                                            \
             const int so_ = (oW) + ((which) & 1) * 4 * w_row8;                                              \
             if constexpr (((PCS) & 1) != 0) P256_BLDS(srdW, w_vo, so_, dst_);                               \
@@ -255,7 +253,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     }
 // counted wait: P256_INFLIGHT = the pieces of the younger slot loads that stay in flight (four slots and a half: 9); POST = the stores and pieces of the
 // previous tile's epilogue are younger than the slot waited for
-#define P256_WAIT(POST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((POST) ? P256_INFLIGHT + EX : P256_INFLIGHT) : "memory")
+// WHICH = which of the K-tile's three waits (0, 1: behind the A stagings of phases 0 / 1; 3: behind W n1's in phase 3). With two
+// operations per slot and wave they all leave 10 younger operations in flight (6 + 2w, 6 + 2w, 4 + 3w for w = 2 operations
+// per W slot); an fp8 W slot is ONE operation per wave (w = 1): 8, 8, 7.
+#define P256_WAIT(POST, WHICH)                                                                                 \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((W8 ? ((WHICH) == 3 ? P256_INFLIGHT - 3 : P256_INFLIGHT - 2) : P256_INFLIGHT) + ((POST) ? EX : 0)) : "memory")
 #define P256_BARRIER()                                                \
     {                                                                 \
         __builtin_amdgcn_sched_barrier(0);                            \
@@ -280,14 +282,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         P256_READ_W(B, 0);                                                                                  \
         P256_STAGE(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0); /* A m1 of K-tile t+1 */                                          \
         P256_LATE_READS_DONE();                                                                             \
-        P256_WAIT(P0);                    /* retires W n1 of this K-tile */                                 \
+        P256_WAIT(P0, 0);                 /* retires W n1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
         P256_MMA(0, 0, P256_STAGE_MID(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0));                               \
         P256_BARRIER();                                                                                     \
         P256_READ_W(B, 1);                                                                                  \
         P256_STAGE(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                          \
         P256_LATE_READS_DONE();                                                                             \
-        P256_WAIT(P1);                    /* retires A m1 of this K-tile */                                 \
+        P256_WAIT(P1, 1);                 /* retires A m1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
         P256_MMA(0, 1, P256_STAGE_MID(0, B, oA2, oW2, true));                                               \
         P256_BARRIER();                                                                                     \
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         P256_BARRIER();                                                                                     \
         P256_STAGE(3, B, oA2, oW2, true);       /* W n1 of K-tile t+2 */                                          \
         P256_FIN_HOOK(FIN);                                                                                 \
-        P256_WAIT(P3);                    /* retires A m0 / W n0 of the next K-tile */                      \
+        P256_WAIT(P3, 3);                 /* retires A m0 / W n0 of the next K-tile */                      \
         P256_BARRIER();                                                                                     \
         if constexpr (!(HALF)) { P256_MMA(1, 0, P256_STAGE_MID(3, B, oA2, oW2, true)); }                    \
         else { P256_STAGE_MID(3, B, oA2, oW2, true); }                                                      \
@@ -629,11 +631,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     int o2 = 0, k2 = 1;
     {
         char* d0 = smem + stage_dst;
-        // (the same two operations per slot and wave as in the loop, in the same order: the counted waits depend on it)
+        // (the same operations per slot and wave as in the loop, in the same order: the counted waits depend on it)
 #define P256_PRO_W(which, b, oW)                                                                                      \
         if constexpr (W8) {                                                                                          \
             P256_BLDS(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8, smem + P256_SLOT(which, b) + wave * 1024);      \
-            P256_BLDS4(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8, smem + P256_SLOT(which, b) + 8192 + wave * 256); \
         } else {                                                                                                     \
             P256_BLDS(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8, d0 + P256_SLOT(which, b));                      \
             P256_BLDS(srdW, w_vo, (oW) + ((which) & 1) * 4 * w_row8 + w_row8, d0 + P256_SLOT(which, b) + 1024);      \
@@ -650,7 +651,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     oA1 = oA2; oW1 = oW2;
     oA2 += GEMM_BK * (int)sizeof(IN); oW2 += GEMM_BK * WELT;
     k2 = 2;
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    // all but the five youngest slot loads (4 + 3w operations: 10, or 7 with one operation per fp8 W slot)
+    if constexpr (W8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     P256_BARRIER();
     if (wm == 1) P256_BARRIER();
 
@@ -668,13 +671,19 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
         const int g = (bn * 4 + wn) * 4 + fg;
         const int n0 = bn * 256 + wn * 64 + 4 * fg;
         const bool whole = (bn + 1) * 256 <= ep.p0;
+        asm volatile("s_nop 11" ::: "memory");   // the asm maxima below read the accumulators of the tile's last MFMAs (mm_mfma_settle)
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (FILTER == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int m = bm * 256 + wm * 128 + j * 16 + fr;
-                float mx = -INFINITY;
+                float mx = mm_max3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);   // (mm_max*: no canonicalising v_max per operand)
+                mx = mm_max3(mx, acc[0][j][3], acc[1][j][0]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
+                for (int i = 1; i < 4; ++i) {
+                    mx = mm_max3(mx, acc[i][j][1], acc[i][j][2]);
+                    mx = i < 3 ? mm_max3(mx, acc[i][j][3], acc[i + 1][j][0]) : mm_max2(mx, acc[i][j][3]);
+                }
                 mx *= WSCALE;   // (fp8 rows: the codes are 128 x the stored values; a power of two, exact)
                 if (mx >= tau_r[j]) {   // rare: some row of this lane's 16 reaches the query's threshold (tau_r = +inf for pad queries)
 #pragma unroll
@@ -697,11 +706,16 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
         for (int j = 0; j < 8; ++j) {
             float mx = -INFINITY;
             if (whole) {
+                // 16 values: 8 three-way maxima without the canonicalising v_max per operand (mm_max3, common.h)
+                mx = mm_max3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);
+                mx = mm_max3(mx, acc[0][j][3], acc[1][j][0]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    mx = fmaxf(mx, fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3])));
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 1; i < 4; ++i) {
+                    mx = mm_max3(mx, acc[i][j][1], acc[i][j][2]);
+                    mx = i < 3 ? mm_max3(mx, acc[i][j][3], acc[i + 1][j][0]) : mm_max2(mx, acc[i][j][3]);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)

@@ -527,13 +527,83 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
     }
 }
 
+// d = 1024 (ViT-L/14): SIXTEEN consecutive columns per lane — two 16-byte loads, ONE 16-byte store per row and lane (the
+// 8-column form stores 8 bytes: half-width store instructions), a 32-column block = 2 lanes: one xor-shuffle.
+__global__ __launch_bounds__(256) void layernorm16_mxfp8_1024_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, uint8_t* __restrict__ out,
+                                                                     uint8_t* __restrict__ out_scale, int M, int ld_os, float eps) {
+    constexpr int D = 1024, RW = 4;
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (r0 >= M) return;
+    const int c = lane * 16;
+    float gm[16], bb[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c + 4 * i), b = *reinterpret_cast<const f32x4*>(beta + c + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gm[4 * i + e] = g[e]; bb[4 * i + e] = b[e]; }
+    }
+    u32x4 raw[RW][2];
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int r = r0 + j < M ? r0 + j : M - 1;
+        raw[j][0] = *reinterpret_cast<const u32x4*>(x + (size_t)r * D + c);
+        raw[j][1] = *reinterpret_cast<const u32x4*>(x + (size_t)r * D + c + 8);
+    }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        const int r = r0 + j;
+        float v[16];
+        float s = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                v[8 * h + 2 * w] = __uint_as_float(raw[j][h][w] << 16);
+                v[8 * h + 2 * w + 1] = __uint_as_float(raw[j][h][w] & 0xFFFF0000u);
+            }
+            s += ((v[8 * h] + v[8 * h + 1]) + (v[8 * h + 2] + v[8 * h + 3])) + ((v[8 * h + 4] + v[8 * h + 5]) + (v[8 * h + 6] + v[8 * h + 7]));
+        }
+        const float mean = wave_sum(s) * (1.0f / (float)D);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float t = v[e] - mean;
+            q += t * t;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
+        float y[16];
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            y[e] = (v[e] - mean) * rstd * gm[e] + bb[e];
+            amax = fmaxf(amax, fabsf(y[e]));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        int e8;
+        float inv;
+        mx_scale_of(amax, e8, inv);
+        if (r < M) {
+            u32x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk[i] = pack_fp8x4(y[4 * i] * inv, y[4 * i + 1] * inv, y[4 * i + 2] * inv, y[4 * i + 3] * inv);
+            *reinterpret_cast<u32x4*>(out + (size_t)r * D + c) = pk;
+            if ((lane & 1) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
+        }
+    }
+}
+
 static int launch_layernorm_mxfp8(hipStream_t st, const void* x, bool x_bf16, const float* gamma, const float* beta, uint8_t* out,
                                   uint8_t* out_scale, int M, int d, float eps) {
     if (d > 1024 || (d % 32)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "layernorm_mxfp8: d=%d (need d <= 1024, d %% 32 == 0)", d);
     MM_PROF(x_bf16 ? "layernorm16_mxfp8" : "layernorm_mxfp8", st, 8.0 * M * d, (double)M * d * (x_bf16 ? 3 : 5));
     if (x_bf16 && (d == 512 || d == 1024) && mmiss_option("ln_mxfp8_wide", 1) != 0) {
         const int grid = (M + 15) / 16;
-        if (d == 1024)
+        if (d == 1024 && mmiss_option("ln_mxfp8_wide", 1) == 1)
+            hipLaunchKernelGGL(layernorm16_mxfp8_1024_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
+                               beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
+        else if (d == 1024)   // (option ln_mxfp8_wide = 2: the 8-columns-per-lane form, A/B)
             hipLaunchKernelGGL(layernorm16_mxfp8_wide_kernel<2>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
                                beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
         else

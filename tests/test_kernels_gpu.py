@@ -290,7 +290,8 @@ def _attn_ref(torch, qkv, B, T, H, causal):
 
 
 @pytest.mark.parametrize("B,T,H,causal", [(3, 50, 12, 0), (2, 77, 8, 1), (2, 16, 2, 1), (1, 5, 2, 0), (2, 257, 4, 0), (1, 248, 3, 1), (5, 33, 2, 1),
-                                            (2, 150, 2, 1), (1, 288, 2, 0), (40, 129, 16, 0)])
+                                            (2, 150, 2, 1), (1, 288, 2, 0), (40, 129, 16, 0),
+                                            (64, 257, 16, 0), (128, 130, 12, 1)])
 def test_attention(env, B, T, H, causal):
     torch, _lib, lib = env
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
@@ -303,6 +304,13 @@ def test_attention(env, B, T, H, causal):
     err = (ctx.float() - ref).abs().max().item()
     assert err < 2e-2, err
     assert torch.isfinite(ctx.float()).all()
+    # repeatable bits (round 4: inline-asm maxima read MFMA results inside the hazard window until an s_nop was put in front of
+    # them — the softmax offsets, and with them the bf16 roundings of P, then differed from launch to launch)
+    for _ in range(3):
+        ctx2 = torch.zeros_like(ctx)
+        _lib.check(lib.mmiss_dbg_attention(0, None, qkv.data_ptr(), ctx2.data_ptr(), B, T, H, causal))
+        torch.cuda.synchronize()
+        assert torch.equal(ctx, ctx2)
 
 
 def test_attention_peaked_softmax(env):
@@ -319,6 +327,34 @@ def test_attention_peaked_softmax(env):
     torch.cuda.synchronize()
     ref = _attn_ref(torch, qkv, B, T, H, False)
     assert torch.allclose(ctx.float(), ref, atol=1e-2)
+
+
+@pytest.mark.parametrize("causal", [0, 1])
+def test_attention_long_form_rescale_branch(env, causal):
+    """The long-sequence kernel (T > 128) is a ONE-pass online softmax whose offset is raised — and the output tile and the
+    denominator rescaled — only when a score exceeds it by more than 2^8: a rare, data-dependent branch (guide rule 26:
+    it needs an input that FORCES it and a full independent reference). Keys 40, 133 and 200 carry growing spikes against
+    every query (logits ~ +12, +40, +90 over the rest: each raises the maximum past the threshold in a later key tile),
+    a fourth query-specific spike sits at key 250 for queries 100..119 only, and key 7 is a mild +3 that must NOT rescale.
+    Against the fp32 softmax of torch on the whole tensor."""
+    torch, _lib, lib = env
+    B, T, H = 2, 257, 3
+    g = torch.Generator(device="cuda").manual_seed(77)
+    qkv = torch.randn(B * T, 3 * H * 64, device="cuda", generator=g) * 0.5
+    x = qkv.view(B, T, 3, H, 64)
+    x[:, :, 0, :, 0] = 4.0                       # every query: component 0 = 4
+    for key, val in ((7, 6.0), (40, 24.0), (133, 80.0), (200, 180.0)):
+        x[:, key, 1, :, 0] = val                 # logit += 4 * val / 8
+    x[:, 100:120, 0, :, 1] = 8.0                 # queries 100..119: a second direction ...
+    x[:, 250, 1, :, 1] = 120.0                   # ... that only key 250 answers (+120 for them, 0 for the others' component 1 ~ N(0, .5))
+    qkv = _bf16(qkv)
+    ctx = torch.zeros(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.mmiss_dbg_attention(0, None, qkv.data_ptr(), ctx.data_ptr(), B, T, H, causal))
+    torch.cuda.synchronize()
+    ref = _attn_ref(torch, qkv, B, T, H, bool(causal))
+    assert torch.isfinite(ctx.float()).all()
+    err = (ctx.float() - ref).abs().max().item()
+    assert err < 2e-2, err
 
 
 @pytest.mark.parametrize("S,P", [(224, 32), (64, 32), (224, 14)])

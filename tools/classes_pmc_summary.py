@@ -12,16 +12,18 @@ import sys
 CLASSES = [  # (class, regex over the kernel name as rocprofv3 prints it — demangled where its demangler copes —, source run)
     ("gemm_bf16_lnfold_qgelu_p256 (FC1)", r"gemm256p_kernel(ILi8E|<8,)", "bench"),
     ("gemm_bf16_lnfold_bias_p256 (QKV)", r"gemm256p_kernel(ILi7E|<7,)", "bench"),
-    ("gemm_bf16_bias_resid16_p160 (out-proj + FC2)", r"gemm160p_kernel(ILi9E|<9,)", "bench"),
+    ("gemm_bf16_bias_resid16_p160_k3072 (FC2)", r"gemm160p_kernel(ILi9ELi0ELi48E|<9, 0, 48>)", "bench"),
+    ("gemm_bf16_bias_resid16_p160_k768 (out-proj)", r"gemm160p_kernel(ILi9ELi0ELi12E|<9, 0, 12>)", "bench"),
     ("gemm_bf16_patch_p160", r"gemm160p_kernel(ILi4E|<4,)|gemm16_kernelIDF16bLi160ELi4E", "bench"),
     ("attention (B/32: 50 tokens, 4 heads per workgroup)", r"attention_heads_kernel", "bench"),
     ("score_gemm_f16 (step query, 256 x 100k)", r"gemm256s_kernelIDF16_|gemm(256|16)_kernelIDF16_", "bench"),
-    ("gemm_bf16_bias_qgelu_p256 (L/14 FC1, bf16 leg)", r"gemm256p_kernel(ILi2E|<2,)", "fp8"),
-    ("gemm_bf16_bias_p256 (L/14 QKV, bf16 leg)", r"gemm256p_kernel(ILi1E|<1,)", "fp8"),
-    ("gemm_bf16_bias_resid16 (L/14 out-proj, both legs)", r"gemm16_kernelIDF16bLi1[0-9]+ELi9E", "fp8"),
-    ("gemm_bf16_bias_resid16_p160 (L/14 FC2, bf16 leg)", r"gemm160p_kernel(ILi9E|<9,)", "fp8"),
-    ("gemm8 (fp8 block-scaled GEMMs, L/14 bs 128)", r"gemm8_kernel", "fp8"),
-    ("attention (L/14: 257 tokens)", r"attention", "fp8"),
+    ("gemm_bf16_lnfold_qgelu_p256 (L/14 FC1, bf16 leg, finished statistics)", r"gemm256p_kernel(ILi8ELi1E|<8, 1,)", "fp8"),
+    ("gemm_bf16_lnfold_bias_p256 (L/14 QKV, bf16 leg, finished statistics)", r"gemm256p_kernel(ILi7ELi1E|<7, 1,)", "fp8"),
+    ("gemm_bf16_bias_resid16 (L/14 out-proj, bf16 leg)", r"gemm16_kernelIDF16bLi1[0-9]+ELi9E", "fp8"),
+    ("gemm_bf16_bias_resid16_p160_k4096 (L/14 FC2, bf16 leg)", r"gemm160p_kernel(ILi9ELi0ELi64E|<9, 0, 64>)", "fp8"),
+    ("gemm8 (fp8 block-scaled GEMMs incl. the out-projection, L/14 bs 128)", r"gemm8_kernel", "fp8"),
+    ("attention_long (L/14: 257 tokens, bf16 + MXFP8 output)", r"attention_long_kernel", "fp8"),
+    ("layernorm16 -> MXFP8 (L/14, 16 columns per lane)", r"layernorm16_mxfp8", "fp8"),
 ]
 COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAVES",
             "GRBM_GUI_ACTIVE", "SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",

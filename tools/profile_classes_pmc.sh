@@ -5,7 +5,7 @@
 # each rocprofv3 run with --kernel-trace + --pmc only (gpurun refuses --pmc next to the API trace domains).
 # Usage (through gpurun): bash tools/profile_classes_pmc.sh r03   ->  gpurun_out/classes_pmc_r03/summary.csv
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/classes_pmc_$TAG

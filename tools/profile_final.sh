@@ -2,7 +2,7 @@
 # Final artefact set of a round, one call on one box: GPU test suite, smoke(), the default bench line, and the rocprofv3
 # kernel-trace summary of the same step. Usage (through gpurun): bash tools/profile_final.sh r02
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/final_$TAG

@@ -3,7 +3,7 @@
 # rocprofv3 run with --kernel-trace only (MI355X_MICROARCH.md, HBM section), aggregated by tools/traffic_from_pmc.py.
 # Usage (through gpurun): bash tools/profile_pmc.sh r02
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG

@@ -18,7 +18,9 @@ import sys
 CLASSES = {
     "gemm_bf16_bias_resid": r"gemm16_kernelIDF16bLi160ELi3E",
     "gemm_bf16_bias_resid16": r"gemm16_kernelIDF16bLi160ELi9E",
-    "gemm_bf16_bias_resid16_p160": r"gemm160p_kernel(ILi9E|<9,)",   # round 3: out-projection + FC2 of the bs-256 step (gemm_bf16_p160.h)
+    # round 4: one symbol per K (gemm160p_kernel<9, 0, K/64>): out-projection and FC2 of the bs-256 step apart
+    "gemm_bf16_bias_resid16_p160_k768": r"gemm160p_kernel(ILi9ELi0ELi12E|<9, 0, 12>)",
+    "gemm_bf16_bias_resid16_p160_k3072": r"gemm160p_kernel(ILi9ELi0ELi48E|<9, 0, 48>)",
     "gemm_bf16_patch_p160": r"gemm160p_kernel(ILi4E|<4,)",
     "gemm_bf16_bias_resid_pruned": r"gemm16_kernelIDF16bLi128ELi3E",
     "gemm_bf16_bias_qgelu": r"gemm16_kernelIDF16bLi192ELi2E",
@@ -35,7 +37,7 @@ CLASSES = {
     "score_gemm_f16": r"gemm256_kernelIDF16_Li5E",
     "scan_topk_f16": r"scan_topk_kernelIDF16_",
     "layernorm": r"layernorm_kernel(<true>|ILb1E)",
-    "attention": r"attention(_heads)?_kernel(<|ILi)",
+    "attention": r"attention(_heads|_long)?_kernel(<|ILi)",
     "im2col": r"im2col_kernel(<|ILb)",
 }
 ALGORITHMIC = {  # bytes per launch the kernel must move, averaged over the shapes in the class
@@ -43,7 +45,7 @@ ALGORITHMIC = {  # bytes per launch the kernel must move, 
     # the new residual rows (19.7 MB) + their partial LayerNorm statistics (1.2 MB) that replace the LayerNorm pass
     # bf16 residual stream: out-proj 19.7 (A) + 1.2 (W) + 2 x 19.7 (stream) + 1.2 (stats) = 61.5 MB, FC2 78.6 + 4.7 + 39.3 + 1.2
     # = 123.8 MB -> class average 92.7 MB
-    "gemm_bf16_bias_resid16": 92.7e6, "gemm_bf16_bias_resid16_p160": 92.7e6,
+    "gemm_bf16_bias_resid16": 92.7e6, "gemm_bf16_bias_resid16_p160_k768": 61.5e6, "gemm_bf16_bias_resid16_p160_k3072": 123.8e6,
     "gemm_bf16_bias_resid": 151.6e6, "gemm_bf16_bias_qgelu": 103.0e6, "gemm_bf16_bias": 82.2e6,
     "gemm_bf16_lnfold_qgelu": 104.3e6, "gemm_bf16_lnfold_bias": 83.5e6,
     # FC1 12800 x 3072 x 768: 19.7 (A) + 4.7 (W) + 78.6 (out) + 1.2 (row statistics) MB; QKV x 2304: 19.7 + 3.5 + 59.0 + 1.2

@@ -2,7 +2,7 @@
 """After `bash tools/profile_final.sh rNN`, `bash tools/profile_pmc.sh rNN` and `bash tools/profile_classes_pmc.sh rNN` on the
 GPU box: copy the merged artefacts from gpurun_out/ into profiles/ and (re)write the round's section of profiles/README.md FROM
 those files — every number in that section is read from a committed JSON / CSV, none is typed in.
-Usage: python tools/update_profiles.py r03"""
+Usage: python tools/update_profiles.py r04"""
 import csv
 import json
 import os
@@ -10,7 +10,7 @@ import re
 import shutil
 import sys
 
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 for src, dst in ((f"final_{TAG}/bench_line.json", f"{TAG}_bench_line.json"),
@@ -42,21 +42,22 @@ ktot = sum(float(x["TotalDurationNs"]) for x in stats if "at::native" not in x["
 r, l, c = d["retrieval"], d["l14"], d["cpu_baseline"]
 q1, qk, f = r["Q1"], r["Q1024"], l["fp8"]
 rows = [("folded FC1 `gemm256p_kernel<8,3,0,0>` (persistent 256²)", "gemm_bf16_lnfold_qgelu_p256", r"gemm256p_kernel(ILi8E|<8,)", "gemm_bf16_lnfold_qgelu_p256"),
-        ("FC2 on the bf16 stream `gemm160p_kernel<9,0>` (160 × 256, one round)", "gemm_bf16_bias_resid16_p160_k3072", None, "gemm_bf16_bias_resid16_p160"),
+        ("FC2 on the bf16 stream `gemm160p_kernel<9,0,48>` (160 × 256, one round)", "gemm_bf16_bias_resid16_p160_k3072", r"gemm160p_kernel(ILi9ELi0ELi48E|<9, 0, 48>)", "gemm_bf16_bias_resid16_p160_k3072"),
         ("folded QKV `gemm256p_kernel<7,3,0,0>`", "gemm_bf16_lnfold_bias_p256", r"gemm256p_kernel(ILi7E|<7,)", "gemm_bf16_lnfold_bias_p256"),
-        ("out-projection `gemm160p_kernel<9,0>`", "gemm_bf16_bias_resid16_p160_k768", None, "gemm_bf16_bias_resid16_p160"),
+        ("out-projection `gemm160p_kernel<9,0,12>`", "gemm_bf16_bias_resid16_p160_k768", r"gemm160p_kernel(ILi9ELi0ELi12E|<9, 0, 12>)", "gemm_bf16_bias_resid16_p160_k768"),
         ("`attention_heads_kernel<2,false,4>`", "attention", r"attention_heads_kernel", "attention")]
 table = ""
 for label, kname, rx, tcls in rows:
     k = K[kname]
-    prof = f"{rp(rx):.1f}" if rx else f"class average {rp('gemm160p_kernel(ILi9E|<9,)'):.1f}"
+    prof = f"{rp(rx):.1f}"
     t = T.get(tcls, {})
-    ratio = f"{t['traffic_bytes'] / 1e6:.0f} MB" + (f" = {t['ratio_to_algorithmic']:.2f} ×" if "ratio_to_algorithmic" in t else "")
-    mfma = pm(kname.split("_k")[0] if "p160" in kname else kname, "matrix_pipe_busy_share_of_kernel_time")
+    ratio = (f"{t['traffic_bytes'] / 1e6:.0f} MB" + (f" = {t['ratio_to_algorithmic']:.2f} ×" if "ratio_to_algorithmic" in t else "")) if t else "—"
+    mfma = pm(kname, "matrix_pipe_busy_share_of_kernel_time")
     table += (f"| {label} | {k['launches'] // d['steps']} | {k['avg_us']:.1f} ({prof}) | {k['tflops'] or 0:.0f} | {100 * k['share']:.1f} % | "
               f"{ratio} | {100 * mfma:.0f} % |\n")
 roof = d["roofline"]
-text = f"""# profiles/ — round 3 (MI355X, gfx950, ROCm 7.2, one GPU via gpurun)
+c1, cq, f8r = d["config1_self_index"], r["clustered_Q1024"], r["f8_rows"]
+text = f"""# profiles/ — round 4 (MI355X, gfx950, ROCm 7.2, one GPU via gpurun)
 
 The `{TAG}_*` files come from the last code commit of the round: `bash tools/profile_final.sh {TAG}` (GPU test suite, smoke, the default
 bench line, the two rocprofv3 kernel-trace summaries), `bash tools/profile_pmc.sh {TAG}` (FETCH_SIZE and WRITE_SIZE, one run each)
@@ -70,12 +71,16 @@ ViT-L/14 bs-128 encode in bf16 and fp8); this section is generated from them by 
 | `{TAG}_retrieval_kernel_stats.csv` | the same for cosine top-10 over 10M × 512 f16 at Q = 1 and Q = 1024 (`tools/retrieval_profile.py`) |
 | `{TAG}_traffic.json` | fabric bytes per launch and kernel class: `--pmc FETCH_SIZE` (× 2, gfx950) + `--pmc WRITE_SIZE`, separate runs (`tools/traffic_from_pmc.py`) |
 | `{TAG}_gemm_pmc_summary.csv` | per kernel class: SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_INST_ANY, SQ_LDS_BANK_CONFLICT, SQ_WAVE_CYCLES, SQ_WAVES, GRBM_GUI_ACTIVE; second pass SQ_INST_CYCLES_VMEM_RD / _WR (gfx950 has no SQ_INST_CYCLES_VMEM), SQ_INSTS_VMEM_RD / _WR, SQ_ACTIVE_INST_VMEM, SQ_WAIT_INST_LDS, SQ_ACTIVE_INST_LDS — the four GEMM classes of the step, attention, the step's score GEMM, and from the L/14 run the bf16 GEMM classes, `gemm8_kernel` (fp8) and the 257-token attention (`tools/classes_pmc_summary.py`) |
-| `gemm_p256_r03.txt` | what was measured while the persistent 256² kernel, the (removed) stream-K kernel and the 160 × 256 kernel were built: scaling, PMC, ablations, tile orders, the loop against the guide's template, what bounds each loop |
+| `gemm_p256_r03.txt` | (round 3) what was measured while the persistent 256² kernel, the (removed) stream-K kernel and the 160 × 256 kernel were built |
+| `attention_l14_r04.txt`, `query_q1_r04.txt` | (round 4) the long attention kernel ablated (K/V staging alone, query tiles alone, waves per workgroup, the removed register prefetch) and the one-query options (scan slabs, merge levels) |
 
 Headline (`{TAG}_bench_line.json`): **{d['value'] / 1e3:.1f} k images/s** ViT-B/32 encode @ bs 256 + cosine top-10 of every embedding vs 100k × 512 f16
-({d['ms_per_step']:.3f} ms/step, {d['encode_tflops']:.0f} TFLOP/s of executed encode work; round 2: 84.6 k by the driver's clock), one batch at a time, steps
+({d['ms_per_step']:.3f} ms/step, {d['encode_tflops']:.0f} TFLOP/s of executed encode work; round 3: 90.3 k by the driver's clock), one batch at a time, steps
 pipelined one deep on one stream ({d['config']['ms_per_step_unpipelined']:.3f} ms/step with the synchronous query). Two batches in flight
 (`two_batches_in_flight`): **{d['two_batches_in_flight']['images_per_s'] / 1e3:.1f} k images/s**. Kernel time per step in the profiled trace: {ktot:.2f} ms — the step is the sum of its kernels.
+The same step on configs[1]'s OWN index (`config1_self_index`: the embeddings of {d['config']['workload'].split('vs a ')[1].split('x')[0]} seeded images, every query widened by one
+threshold pass): **{c1['images_per_s'] / 1e3:.1f} k images/s**, {c1['ms_per_step']:.3f} ms/step = {c1['vs_headline_step']:.3f} × the headline step; query stage {c1['query_stage_ms']['first_pass_plus_widen']:.3f} ms against
+{c1['query_stage_ms']['first_pass_only_guard_off']:.3f} ms for the unproven first pass; {c1['exactness_per_step']['swept_rows'] / 256:.0f} rows re-ranked per query; every query finds itself first: {c1['every_query_finds_itself_first']}.
 
 | kernel class (rocprofv3 symbol) | calls/step | avg µs: HIP events in the bench (rocprofv3) | TFLOP/s | share | fabric bytes per launch (class) | matrix pipes busy |
 |---|---|---|---|---|---|---|
@@ -84,13 +89,17 @@ pipelined one deep on one stream ({d['config']['ms_per_step_unpipelined']:.3f} m
 peak over {roof['sampled_launches_in_timed_region']} sampled launches ({roof['avg_launch_us']:.1f} µs each; {roof['arithmetic_intensity_flop_per_byte']:.0f} flop/B against a ridge of {roof['ridge_flop_per_byte']:.0f}: compute side).
 
 Retrieval, 10M × 512 f16 on one GPU: Q = 1 {q1['ms_per_batch']:.3f} ms per query (scan kernel {q1['scan_kernel']['avg_ms']:.3f} ms = {q1['scan_kernel']['hbm_gbs'] / 1e3:.2f} TB/s = {100 * q1['scan_kernel']['hbm_frac']:.1f} % of the
-8 TB/s spec); Q = 16 {r['Q16']['ms_per_batch']:.2f} ms; Q = 1024 **{qk['ms_per_batch']:.2f} ms per batch** (round 2: 10.66): threshold-filtered score GEMM on the staggered loop
+8 TB/s spec); Q = 16 {r['Q16']['ms_per_batch']:.2f} ms; Q = 1024 **{qk['ms_per_batch']:.2f} ms per batch** (round 3: 9.46–9.60): threshold-filtered score GEMM on the staggered loop
 {qk['kernel_ms']['score_gemm_f16']:.2f} ms = {qk['score_gemm']['tflops'] / 1e3:.2f} PFLOP/s f16 = {100 * qk['score_gemm']['mfma_frac']:.1f} % of peak, sample pass {qk['kernel_ms']['score_gemm_f16_sample']:.2f}, select {qk['kernel_ms']['select_topk']:.2f}, merges {qk['kernel_ms']['merge_lists']:.2f}, rerank {qk['kernel_ms']['rerank']:.2f}.
-Exactness accounting over the run: {d['exactness']['queries']} + {r['exactness']['queries']} queries served, {d['exactness']['widened'] + r['exactness']['widened']} widened.
-The same rows stored as fp8 (`MMISS_F8`, `retrieval.f8_rows`): Q = 1 {r['f8_rows']['Q1']['ms_per_batch']:.3f} ms = {r['f8_rows']['Q1']['mvec_per_s'] / 1e3:.1f} G vec/s (scan {r['f8_rows']['Q1']['scan_kernel']['hbm_gbs'] / 1e3:.2f} TB/s over 5.1 GB), Q = 16 {r['f8_rows']['Q16']['ms_per_batch']:.2f} ms.
+Exactness accounting over the run: {d['exactness']['queries']} + {r['exactness']['queries']} queries served on the random indexes, {d['exactness']['widened'] + r['exactness']['widened']} widened;
+`retrieval.check`: first query identical in ids and distance bits across the Q = 1 / 16 / 1024 legs: {r['check']['first_query_ids_and_distance_bits_identical_across_Q1_Q16_Q1024']}.
+A CLUSTERED 10M-row index (pairwise cosine 0.99) at Q = 1024, every query widened by one threshold pass: {cq['ms_per_batch']:.2f} ms per batch
+against {cq['first_pass_only_ms']:.2f} ms for the first pass alone ({cq['ratio_to_first_pass']:.2f} ×), {cq['per_batch']['swept_rows'] // 1024} rows re-ranked per query.
+The same rows stored as fp8 (`MMISS_F8`, `retrieval.f8_rows`): Q = 1 {f8r['Q1']['ms_per_batch']:.3f} ms = {f8r['Q1']['mvec_per_s'] / 1e3:.1f} G vec/s (scan {f8r['Q1']['scan_kernel']['hbm_gbs'] / 1e3:.2f} TB/s over 5.1 GB), Q = 16 {f8r['Q16']['ms_per_batch']:.2f} ms,
+Q = 1024 {f8r['Q1024']['ms_per_batch']:.2f} ms (round 4: the strip score GEMM on fp8 rows, {f8r['Q1024']['score_gemm']['tflops'] / 1e3:.2f} PFLOP/s).
 
-ViT-L/14 geometry of the reference's checkpoint, bs 128: bf16 **{l['images_per_s_bs128'] / 1e3:.2f} k images/s** ({l['image_tflops']:.0f} TFLOP/s; round 2: 5.47 k), 1 − cos vs the fp32 oracle
-{l['max_1_minus_cos_vs_fp32_oracle']['image']:.1e} (image) / {l['max_1_minus_cos_vs_fp32_oracle']['text']:.1e} (text); fp8 vision tower **{f['images_per_s_bs128'] / 1e3:.2f} k images/s**, 1 − cos vs the oracle {f['max_1_minus_cos_vs_fp32_oracle']['image']:.1e}
+ViT-L/14 geometry of the reference's checkpoint, bs 128: bf16 **{l['images_per_s_bs128'] / 1e3:.2f} k images/s** ({l['image_tflops']:.0f} TFLOP/s; round 3: 5.81 k), 1 − cos vs the fp32 oracle
+{l['max_1_minus_cos_vs_fp32_oracle']['image']:.1e} (image) / {l['max_1_minus_cos_vs_fp32_oracle']['text']:.1e} (text); fp8 vision tower **{f['images_per_s_bs128'] / 1e3:.2f} k images/s** (round 3: 7.68 k), 1 − cos vs the oracle {f['max_1_minus_cos_vs_fp32_oracle']['image']:.1e}
 (text tower stays on bf16 under the fp8 setting: {f['max_1_minus_cos_vs_fp32_oracle']['text']:.1e}). ViT-B/32 with the opt-in fp8 GEMMs: {d['fp8_gemms']['images_per_s'] / 1e3:.1f} k images/s at 1 − cos = {d['fp8_gemms']['max_1_minus_cos_vs_bf16_path']:.1e}
 from the bf16 embeddings of the same batch.
 
@@ -103,22 +112,23 @@ CPU baseline on the box's host ({c['cores']} threads): {c['value']:.1f} {c['unit
 """
 p = f"{P}/README.md"
 s = open(p).read()
-marker = "# profiles/ — round 3"
+marker = "# profiles/ — round 4"
 if marker in s:
-    s = s[s.index("# profiles/ — round 2"):]
+    s = s[s.index("# profiles/ — round 3"):]
 open(p, "w").write(text + s)
 # ---- the numbers paragraph of the repository README, from the same artefacts
 rp_ = os.path.join(ROOT, "README.md")
 rs = open(rp_).read()
-para = f"""Round-3 numbers (one MI355X; boxes differ by ±3–5 %; `profiles/README.md`, generated from the committed artefacts): {d['value'] / 1e3:.1f} k images/s
+para = f"""Round-4 numbers (one MI355X; boxes differ by ±3–5 %; `profiles/README.md`, generated from the committed artefacts): {d['value'] / 1e3:.1f} k images/s
 ViT-B/32 encode @ bs 256 incl. top-10 vs a 100k x 512 index ({d['ms_per_step']:.2f} ms/step, the sum of its kernels),
-{d['two_batches_in_flight']['images_per_s'] / 1e3:.1f} k with two batches in flight (`mmiss_amd/pipeline.py`); cosine top-10 over 10M x 512 f16: {q1['mvec_per_s'] / 1e3:.1f} G vec/s at Q=1 (scan at
+{d['two_batches_in_flight']['images_per_s'] / 1e3:.1f} k with two batches in flight (`mmiss_amd/pipeline.py`), {c1['images_per_s'] / 1e3:.1f} k on the index of its OWN embeddings (every query widened by one threshold pass); cosine top-10 over 10M x 512 f16: {q1['mvec_per_s'] / 1e3:.1f} G vec/s at Q=1 (scan at
 {q1['scan_kernel']['hbm_gbs'] / 1e3:.1f} TB/s), {qk['ms_per_batch']:.1f} ms per 1024-query batch (score matrix never written); {d['text']['texts_per_s'] / 1e3:.0f} k texts/s; {d['single_request']['image_encode_plus_top10_ms_device_resident']:.2f} ms per single image request;
 raw 640x480 uploads at {d['ingest']['images_per_s_device_resident'] / 1e3:.0f} k images/s (resize on the GPU, bit-identical to Pillow); the reference's own ViT-L/14 geometry at
-{l['images_per_s_bs128'] / 1e3:.1f} k images/s in bf16 and {f['images_per_s_bs128'] / 1e3:.1f} k images/s with the vision tower's QKV / MLP GEMMs on the block-scaled fp8 matrix cores
+{l['images_per_s_bs128'] / 1e3:.1f} k images/s in bf16 and {f['images_per_s_bs128'] / 1e3:.1f} k images/s with the vision tower's four projections on the block-scaled fp8 matrix cores
 (1 − cos vs the fp32 oracle {f['max_1_minus_cos_vs_fp32_oracle']['image']:.1e}: inside the 1e-3 tolerance; the text tower stays on bf16 under the fp8 setting, its fp8
 form is an explicit per-tower opt-in).
 """
-a_, b_ = rs.index("Round-3 numbers (one MI355X"), rs.index("Parity: bf16 embeddings within 1e-3 cosine")
+a_ = rs.index("Round-4 numbers (one MI355X") if "Round-4 numbers (one MI355X" in rs else rs.index("Round-3 numbers (one MI355X")
+b_ = rs.index("Parity: bf16 embeddings within 1e-3 cosine")
 open(rp_, "w").write(rs[:a_] + para + rs[b_:])
 print(f"{TAG}: {d['value']:.0f} images/s, {d['ms_per_step']} ms/step; README sections written from the artefacts")
