@@ -54,7 +54,9 @@ __device__ __forceinline__ f16x8 p256_widen_f8(u32x2 w) {
 
 // DBG (timing experiments only, EXPERIMENTS builds, tools/gemm_p256_ablate.py; results are wrong by construction), a
 // compile-time mask: 1 = no MFMAs, 2 = no staging inside the loop, 4 = no fragment reads, 8 = every tile loads tile (0, 0)
-// (operands L2-hot), 16 = no epilogue, 32 = epilogue without its stores, 64 = no barriers
+// (operands L2-hot), 16 = no epilogue, 32 = epilogue without its stores, 64 = no barriers, 128 = the loop on
+// v_mfma_f32_32x32x16_bf16 (8 instructions of 8 passes per phase instead of 16 of 4; the same fragment reads, the same LDS
+// layout; the epilogue reads the accumulators as if they had the 16 x 16 layout)
 // STYLE: how the epilogue gets from "a lane holds 4 consecutive columns of one row" to wide stores: 0 = a 16 x 64 transpose
 // per wave through a private 2 KB LDS patch, whole 128-byte rows per store instruction; 1 = two v_permlane16_swap per
 // 16 x 32 block, 8 consecutive columns per lane, 64-byte row segments (two adjacent instructions per line).
@@ -202,16 +204,44 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         ab[s] = (wm * 64 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
         wb[s] = P256_SLOT(2, 0) + (wn * 32 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
     }
+    // (DBG & 128: lane l feeds row l & 31, k = 16 ks + 8 (l >> 5) .. + 7 of k step ks = 0 .. 3; one base per k step)
+    uint32_t ab32[4], wb32[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        ab32[s] = (wm * 64 + (lane & 31)) * 128 + (((2 * s + (lane >> 5)) ^ (lane & 7)) << 4);
+        wb32[s] = P256_SLOT(2, 0) + (wn * 32 + (lane & 31)) * 128 + (((2 * s + (lane >> 5)) ^ (lane & 7)) << 4);
+    }
     frag am[4][2];
     frag wq[2][2][2];
     f32x4 acc[4][8];
+    f32x16 acc32[2][4];   // (DBG & 128) [n quarter][m quarter x 2 + 32-row block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+    auto acc_get = [&](int i, int j, int r) -> float {
+        if constexpr ((DBG & 128) != 0) return acc32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + r];
+        else return acc[i][j][r];
+    };
+    auto acc_zero = [&](int i, int j) {
+        if constexpr ((DBG & 128) != 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc32[i >> 1][j >> 1][((i & 1) * 2 + (j & 1)) * 4 + r] = 0.f;
+        } else acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define P256_READ_A(b, mq)                                                                                   \
-    if constexpr (!((DBG & 4) != 0)) {                                                                      \
+    if constexpr ((DBG & 128) != 0) {                                                                       \
+        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                    \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                \
+                am[mb * 2 + (ks >> 1)][ks & 1] = *reinterpret_cast<const frag*>(smem + ab32[ks] + P256_SLOT(mq, b) + mb * 4096); \
+    } else if constexpr (!((DBG & 4) != 0)) {                                                               \
         _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) {                                                  \
             am[mf][0] = *reinterpret_cast<const frag*>(smem + ab[0] + P256_SLOT(mq, b) + mf * 2048);        \
             am[mf][1] = *reinterpret_cast<const frag*>(smem + ab[1] + P256_SLOT(mq, b) + mf * 2048);        \
@@ -223,6 +253,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
             wq[nq][nf][0] = __builtin_bit_cast(frag, p256_widen_f8(*reinterpret_cast<const u32x2*>(smem + wb[0] + P256_SLOT(nq, b) + nf * 1024))); \
             wq[nq][nf][1] = __builtin_bit_cast(frag, p256_widen_f8(*reinterpret_cast<const u32x2*>(smem + wb[1] + P256_SLOT(nq, b) + nf * 1024))); \
         }                                                                                                   \
+    } else if constexpr ((DBG & 128) != 0) {                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                    \
+            wq[nq][ks >> 1][ks & 1] = *reinterpret_cast<const frag*>(smem + wb32[ks] + P256_SLOT(nq, b));   \
     } else if constexpr (!((DBG & 4) != 0)) {                                                               \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                                  \
             wq[nq][nf][0] = *reinterpret_cast<const frag*>(smem + wb[0] + P256_SLOT(nq, b) + nf * 2048);    \
@@ -230,6 +263,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         }                                                                                                   \
     }
 #define P256_MMA_HALF(mq, nq, s)                                                                             \
+    if constexpr ((DBG & 128) != 0) {                                                                       \
+        if constexpr (std::is_same<IN_T, __bf16>::value) {                                                  \
+            _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                                \
+                _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                            \
+                    acc32[nq][(mq) * 2 + mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                     \
+                        wq[nq][s][kq], am[mb * 2 + (s)][kq], acc32[nq][(mq) * 2 + mb], 0, 0, 0);            \
+        }                                                                                                   \
+    } else                                                                                                  \
     _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                        \
         _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                                    \
             acc[(nq) * 2 + nf][(mq) * 4 + mf] = MfmaIn<IN_T>::mma(                                          \
@@ -416,15 +457,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                     float y[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if constexpr (FOLD) y[r] = rs[j] * (acc[i][j][r] - mu[j] * cvec[i][r]) + bias[i][r];
-                        else y[r] = acc[i][j][r] + bias[i][r];
+                        if constexpr (FOLD) y[r] = rs[j] * (acc_get(i, j, r) - mu[j] * cvec[i][r]) + bias[i][r];
+                        else y[r] = acc_get(i, j, r) + bias[i][r];
                         if constexpr (GELU) y[r] = quick_gelu(y[r]);
                     }
                     u32x2 pk;
                     pk[0] = pack_bf16x2(y[0], y[1]);
                     pk[1] = pack_bf16x2(y[2], y[3]);
                     *reinterpret_cast<u32x2*>(patch + wr_off + (((i * 4 + fg) ^ wr_sw) << 3)) = pk;
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc_zero(i, j);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -452,13 +493,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                     float y[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if constexpr (FOLD) y[r] = rs[j] * (acc[i][j][r] - mu[j] * cvec[i][r]) + bias[i][r];
-                        else y[r] = acc[i][j][r] + bias[i][r];
+                        if constexpr (FOLD) y[r] = rs[j] * (acc_get(i, j, r) - mu[j] * cvec[i][r]) + bias[i][r];
+                        else y[r] = acc_get(i, j, r) + bias[i][r];
                         if constexpr (GELU) y[r] = quick_gelu(y[r]);
                     }
                     pk[i][0] = pack_bf16x2(y[0], y[1]);
                     pk[i][1] = pack_bf16x2(y[2], y[3]);
-                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc_zero(i, j);
                 }
                 const int m = cbm * 256 + wm * 128 + hrow + j * 16 + fr;
                 uint16_t* orow = outp + (size_t)(m < ep.m_valid ? m : dump_row) * ep.ldo + colb;
@@ -521,7 +562,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += acc[i][j];
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] += acc_get(i, j, r);
         if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.678f) reinterpret_cast<float*>(ep.out)[tid] = sum[0];
     }
     // the unconditional staging of the last K-tiles is still in flight: LDS must not be handed on with DMA writes pending
@@ -566,6 +609,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     constexpr int WELT = W8 ? 1 : (int)sizeof(IN);
     constexpr float WSCALE = W8 ? 1.0f / 128.0f : 1.0f;
     constexpr int DBG = 0;
+    uint32_t ab32[4], wb32[4]; f32x16 acc32[2][4];   // (named by the loop macros' DBG & 128 branches only: never touched here)
     constexpr bool FOLD = false;
     constexpr int EX = 0;
     const int tid = threadIdx.x;
@@ -789,6 +833,7 @@ static int launch_gemm256p_inst(hipStream_t st, const void* A, const void* W, co
 #define P256_DBG_CASE(D) if (dbg == D) return launch_gemm256p_kern<EPI, XP, 0, D>(st, A, W, ep, M, N, K);
         P256_DBG_CASE(1) P256_DBG_CASE(2) P256_DBG_CASE(4) P256_DBG_CASE(8) P256_DBG_CASE(5) P256_DBG_CASE(6) P256_DBG_CASE(7)
         P256_DBG_CASE(16) P256_DBG_CASE(32) P256_DBG_CASE(64) P256_DBG_CASE(23) P256_DBG_CASE(39) P256_DBG_CASE(87)
+        P256_DBG_CASE(128) P256_DBG_CASE(136) P256_DBG_CASE(144) P256_DBG_CASE(132)
 #undef P256_DBG_CASE
         if (dbg) MM_FAIL(MMISS_ERR_ARG, "gemm_p256_dbg = %d is not compiled", dbg);
     }

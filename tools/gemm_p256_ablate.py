@@ -24,7 +24,9 @@ for M in (256 * 128,):   # 768 / 1536 tiles: 3 / 6 tiles per workgroup exactly
         for name, dbg in (("full", 0), ("hot operands", 8), ("no MFMA", 1), ("no staging", 2), ("no fragment reads", 4),
                           ("no MFMA, no reads", 5), ("no staging, no reads", 6), ("only barriers + epilogue", 7),
                           ("only barriers + epilogue without stores", 7 + 32), ("only barriers", 7 + 16), ("empty loop", 7 + 16 + 64),
-                          ("full without epilogue", 16), ("full without stores", 32), ("full without barriers", 64)):
+                          ("full without epilogue", 16), ("full without stores", 32), ("full without barriers", 64),
+                          ("full", 0), ("32x32x16 MFMA", 128), ("32x32x16 MFMA, hot operands", 136), ("32x32x16 MFMA, no reads", 132),
+                          ("full", 0), ("32x32x16 MFMA", 128)):
             _lib.set_option("gemm_p256_dbg", dbg)
             _lib.check(lib.mmiss_dbg_gemm_p256(0, None, 8, A.data_ptr(), W.data_ptr(), out.data_ptr(), bias.data_ptr(),
                                                cvec.data_ptr(), stats.data_ptr(), 1e-5, M, N, K, M, 30, C.byref(ms)))
