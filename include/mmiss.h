@@ -212,6 +212,10 @@ int mmiss_index_labels(mmiss_index* idx, int64_t* out, int64_t cap);
  * out_labels int64 [Q,k], out_dist float32 [Q,k] = cosine distance 1 - cos, ascending; ties by label
  * ascending. out_count int32 [Q] = min(k, count); unused slots hold label -1 / distance +inf.
  * k larger than count is not an error (the UI's "All" sends 1000 — backend/app/main.py:757).
+ * A vector without a direction — zero norm, or a NaN / Inf component: 0/0 in the normalisation — has no distance to
+ * anything: such a ROW is stored but never returned (out_count then counts the rows that have a distance), such a QUERY has
+ * no results (out_count 0). Not an error; the reference never sends one (backend/app/utils.py:88-99 always hands chromadb a
+ * CLIP embedding). tests/test_index_gpu.py: test_zero_and_non_finite_vectors_are_never_results, all three storage types.
  * Synchronisation: the exactness guard (below) decides on the host whether any query must be widened (the last kernel
  * leaves one flag per query in a pinned host block; no copy-engine operation), so the call waits for its own work on the
  * stream it runs on — also on a caller's stream with device outputs (mmiss_index_set_stream(.., use_own = 0)), and it

@@ -40,7 +40,7 @@ def e4m3_decode(b: np.ndarray) -> np.ndarray:
 
 
 def e4m3_encode(x: np.ndarray) -> np.ndarray:
-    """Round to nearest, ties to even, |x| <= 448 (callers scale first). -> uint8."""
+    """Round to nearest, ties to even, |x| <= 448 (callers scale first); NaN -> 0x7F / 0xFF (the format's NaN). -> uint8."""
     x = np.asarray(x, np.float64)
     a = np.abs(x)
     hi = np.clip(np.searchsorted(_POS, a, side="left"), 0, 126)
@@ -48,6 +48,7 @@ def e4m3_encode(x: np.ndarray) -> np.ndarray:
     dl, dh = a - _POS[lo], _POS[hi] - a
     pick_hi = (dh < dl) | ((dh == dl) & (hi % 2 == 0))
     code = np.where(pick_hi, hi, lo).astype(np.uint8)
+    code = np.where(np.isnan(x), np.uint8(0x7F), code).astype(np.uint8)
     return np.where(np.signbit(x), code | 0x80, code).astype(np.uint8)
 
 

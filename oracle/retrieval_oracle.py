@@ -99,13 +99,20 @@ def query(q_raw: np.ndarray, stored: np.ndarray, labels: np.ndarray, k: int) -> 
         return out_l, out_d, cnt
     d = distances(q_raw, stored)
     for qi in range(Q):
-        kk = min(k, N)
-        if kk < N:
+        # a NaN distance (a zero-norm or non-finite row or query: 0/0 in the normalisation) is never a result — as in
+        # retrieval_oracle.c; the count says how many results there are
+        live = np.nonzero(~np.isnan(d[qi]))[0]
+        kk = min(k, live.size)
+        cnt[qi] = kk
+        if kk == 0:
+            continue
+        dl = d[qi][live]
+        if kk < live.size:
             # every row tied with the kk-th smallest distance must be kept for the label tie-break
-            kth = np.partition(d[qi], kk - 1)[kk - 1]
-            idx = np.nonzero(d[qi] <= kth)[0]
+            kth = np.partition(dl, kk - 1)[kk - 1]
+            idx = live[np.nonzero(dl <= kth)[0]]
         else:
-            idx = np.arange(N)
+            idx = live
         order = np.lexsort((labels[idx], d[qi][idx]))[:kk]
         sel = idx[order]
         out_l[qi, :kk] = labels[sel]

@@ -243,6 +243,57 @@ def test_empty_index_and_errors(mods):
         idx.add(np.zeros((2, 64), np.float32), np.arange(2))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f8"])
+def test_zero_and_non_finite_vectors_are_never_results(mods, dtype):
+    """A zero-norm, NaN or Inf vector has no direction: its normalisation is 0/0, every distance to or from it is NaN. Such a
+    ROW is never returned (the count says how many results there are); such a QUERY has no results (count 0, labels -1,
+    distances +inf). Same in both oracles (retrieval_oracle.py / .c); the reference's chromadb call has no such case
+    (backend/app/utils.py:88-99 always hands over a CLIP embedding)."""
+    import warnings
+
+    from oracle import retrieval_oracle_c as rc
+
+    FlatIndex, _, _, ro = mods
+    N, D = 300, 128
+    c = _corpus(N, D, seed=71)
+    c[5] = 0.0
+    c[17, 3] = np.nan
+    c[40, 9] = np.inf
+    c[41, 9] = -np.inf
+    labels = np.arange(1000, 1000 + N, dtype=np.int64)
+    q = _corpus(7, D, seed=72)
+    q[2] = 0.0
+    q[4, 100] = np.nan
+    q[6, 0] = np.inf
+    idx = FlatIndex(D, dtype)
+    idx.add(c, labels)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")   # (numpy: 0/0, inf/inf in the oracle's normalisation)
+        stored = ro.normalize_rows(c, dtype)
+        assert np.isnan(stored[[5, 17, 40, 41]].astype(np.float32)).any(axis=1).all()
+        for k in (1, 10, N - 4, N, N + 20):
+            lab, dist, cnt = idx.query(q, k)
+            ol, od, oc = ro.query(q, stored, labels, k)
+            cl, cd, cc = rc.query(q, stored, labels, k)
+            np.testing.assert_array_equal(ol, cl)
+            np.testing.assert_array_equal(oc, cc)
+            np.testing.assert_array_equal(od.view(np.uint32), cd.view(np.uint32))
+            np.testing.assert_array_equal(cnt, oc)
+            np.testing.assert_array_equal(lab, ol)
+            np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+            assert (cnt[[2, 4, 6]] == 0).all() and (cnt[[0, 1, 3, 5]] == min(k, N - 4)).all()
+            assert not np.isin(lab, labels[[5, 17, 40, 41]]).any()
+    # the batched (score GEMM) path: the same queries repeated past its threshold
+    qq = np.concatenate([q] * 12)[:80]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lab, dist, cnt = idx.query(qq, 10)
+        ol, od, oc = ro.query(qq, stored, labels, 10)
+    np.testing.assert_array_equal(cnt, oc)
+    np.testing.assert_array_equal(lab, ol)
+    np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+
+
 def test_device_tensors_in_and_out(mods):
     import torch
 

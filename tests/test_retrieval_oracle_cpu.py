@@ -29,6 +29,33 @@ def test_numpy_and_c_oracles_agree_bitwise(rc, dtype, N, D, Q, k):
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f8"])
+def test_zero_and_non_finite_vectors_have_no_distance(rc, dtype):
+    """0/0 in the normalisation: such a row is never a result, such a query has none — in both restatements."""
+    import warnings
+
+    N, D = 60, 128
+    c, q = _rand(N, D, 5), _rand(4, D, 6)
+    c[3] = 0.0
+    c[9, 1] = np.nan
+    c[11, 2] = np.inf
+    q[1] = 0.0
+    q[3, 7] = -np.inf
+    labels = np.arange(N, dtype=np.int64) + 100
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        stored = ro.normalize_rows(c, dtype)
+        for k in (5, N - 3, N + 4):
+            ol, od, oc = ro.query(q, stored, labels, k)
+            cl, cd, cc = rc.query(q, stored, labels, k)
+            np.testing.assert_array_equal(ol, cl)
+            np.testing.assert_array_equal(oc, cc)
+            np.testing.assert_array_equal(od.view(np.uint32), cd.view(np.uint32))
+            assert list(oc) == [min(k, N - 3), 0, min(k, N - 3), 0]
+            assert not np.isin(ol, labels[[3, 9, 11]]).any() and not np.isnan(od).any()
+            assert (ol[1] == -1).all() and np.isinf(od[1]).all()
+
+
 def test_canonical_distance_is_close_to_plain_float64():
     c, q = _rand(2000, 512, 1), _rand(4, 512, 2)
     d = ro.distances(q, ro.normalize_rows(c))
