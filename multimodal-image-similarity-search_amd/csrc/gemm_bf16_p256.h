@@ -270,11 +270,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                     acc32[nq][(mq) * 2 + mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                     \
                         wq[nq][s][kq], am[mb * 2 + (s)][kq], acc32[nq][(mq) * 2 + mb], 0, 0, 0);            \
         }                                                                                                   \
-    } else                                                                                                  \
-    _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                        \
-        _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                                    \
-            acc[(nq) * 2 + nf][(mq) * 4 + mf] = MfmaIn<IN_T>::mma(                                          \
-                wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf]);
+    } else {                                                                                                \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                    \
+            _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                                \
+                acc[(nq) * 2 + nf][(mq) * 4 + mf] = MfmaIn<IN_T>::mma(                                      \
+                    wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf]);                           \
+    }
 // 16 MFMAs with MID (a slot's second LDS-DMA piece, or nothing) issued behind the first eight
 #define P256_MMA(mq, nq, MID)                                                                                \
     if constexpr ((DBG & 1) != 0) {                                                                         \
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         P256_BARRIER();                                                                                     \
         P256_MMA(0, 1, P256_STAGE_MID(0, B, oA2, oW2, true));                                               \
         P256_BARRIER();                                                                                     \
-        if constexpr (!(HALF)) P256_READ_A(B, 1);                                                           \
+        if constexpr (!(HALF)) { P256_READ_A(B, 1); }                                                       \
         P256_STAGE(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
         P256_LATE_READS_DONE();                                                                             \
         P256_BARRIER();                                                                                     \

@@ -743,6 +743,48 @@ struct RerankArgs {
     const int32_t* bmap;      // block b reads candidate list / count bmap[b] (null: b)
 };
 
+// The four partial sums of one lane of the canonical dot product (lane p of a row's 16: elements d = 4p + j + 64 i, i
+// ascending, acc[j] = sum over i in fp64 — the additions of canon_dot in oracle/, in its order). rv / qp point at the lane's
+// first element of the row / the query. The loads of EIGHT 64-element pieces (row and query) are issued before the first
+// multiply-add: with one piece per trip the loop was a chain of D/64 dependent memory round trips per row group — at
+// D = 512 eight of them, ~1 us each: 33 us for the 256 candidate rows of a query (round 4; same bits).
+template <typename T>
+__device__ __forceinline__ void canon_partial_dots(const T* rv, bool live, const float* qp, int D, double (&acc)[4]) {
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    typedef typename std::conditional<sizeof(T) == 1, uint32_t, typename std::conditional<sizeof(T) == 2, u32x2, f32x4>::type>::type piece_t;
+    for (int d0 = 0; d0 < D; d0 += 512) {
+        piece_t w[8];
+        f32x4 qq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            w[u] = piece_t{};   // (zero: fp8 code 0 = +0.0)
+            qq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (d0 + 64 * u < D) {
+                qq[u] = *reinterpret_cast<const f32x4*>(qp + d0 + 64 * u);
+                if (live) w[u] = *reinterpret_cast<const piece_t*>(rv + d0 + 64 * u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (d0 + 64 * u < D) {
+                float rr[4];
+                if constexpr (sizeof(T) == 1) {
+                    f8x4_values(w[u], rr);
+                } else if constexpr (sizeof(T) == 2) {
+                    const _Float16* h = reinterpret_cast<const _Float16*>(&w[u]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rr[j] = (float)h[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rr[j] = w[u][j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (double)qq[u][j] * (double)rr[j];
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -786,29 +828,8 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
         const bool live = row >= 0;  // (no candidate, or an empty index: nothing is dereferenced)
         const T* rv = reinterpret_cast<const T*>(a.rows) + (size_t)(live ? row : 0) * a.D + 4 * p16;
         const float* qp = qv + 4 * p16;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int d0 = 0; d0 < a.D; d0 += 64) {
-            const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + d0);
-            float rr[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (sizeof(T) == 1) {
-                uint32_t w = 0u;   // (code 0 = +0.0)
-                if (live) w = *reinterpret_cast<const uint32_t*>(rv + d0);
-                f8x4_values(w, rr);
-            } else if constexpr (sizeof(T) == 2) {
-                u32x2 w = u32x2{0u, 0u};
-                if (live) w = *reinterpret_cast<const u32x2*>(rv + d0);
-                const _Float16* h = reinterpret_cast<const _Float16*>(&w);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rr[j] = (float)h[j];
-            } else {
-                f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (live) w = *reinterpret_cast<const f32x4*>(rv + d0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rr[j] = w[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (double)qq[j] * (double)rr[j];
-        }
+        double acc[4];
+        canon_partial_dots<T>(rv, live, qp, a.D, acc);
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) {
 #pragma unroll
@@ -901,29 +922,8 @@ __global__ __launch_bounds__(256) void canonical_scan_kernel(const void* __restr
         const int64_t row = r0 + sub;
         const bool live = row < N;
         const T* rv = reinterpret_cast<const T*>(rows) + (size_t)(live ? row : 0) * D + 4 * p16;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int d0 = 0; d0 < D; d0 += 64) {
-            const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + d0);
-            float rr[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (sizeof(T) == 1) {
-                uint32_t w = 0u;   // (code 0 = +0.0)
-                if (live) w = *reinterpret_cast<const uint32_t*>(rv + d0);
-                f8x4_values(w, rr);
-            } else if constexpr (sizeof(T) == 2) {
-                u32x2 w = u32x2{0u, 0u};
-                if (live) w = *reinterpret_cast<const u32x2*>(rv + d0);
-                const _Float16* h = reinterpret_cast<const _Float16*>(&w);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rr[j] = (float)h[j];
-            } else {
-                f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (live) w = *reinterpret_cast<const f32x4*>(rv + d0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rr[j] = w[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + (double)qq[j] * (double)rr[j];
-        }
+        double acc[4];
+        canon_partial_dots<T>(rv, live, qp, D, acc);
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) {
 #pragma unroll
