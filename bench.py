@@ -469,6 +469,30 @@ def main():
                   "resize_crop_gbs": round((B * IH * IW * 3 + B * 224 * 224 * 3) / (rz_ms * 1e-3) / 1e9, 1) if rz_ms else None,
                   "note": "resize(shortest edge 224, bicubic, Pillow-exact) + centre crop + rescale + normalise + ViT-B/32"}
 
+    # ---------------------------------------------------------------- the step with its pixels handed over as HOST buffers
+    # The contract's `value` starts with inputs resident in HBM. The boundary also takes host buffers (the reference's
+    # processor leaves float32 pixel_values on the CPU, backend/app/utils.py:76); this is the PCIe-inclusive rate of the same
+    # step: 154 MB of float32 pixels per batch cross the bus (pageable numpy memory, copied in chunks behind the compute).
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_text:
+        px_host = pixel_batches[0].cpu().numpy()
+
+        def hstep():
+            return index.query(enc.encode_image(px_host), K_TOP)   # host in, host out at both calls
+
+        for _ in range(2):
+            hstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            hstep()
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - t0) / 5
+        pcie = {"images_per_s": round(B / pdt, 1), "ms_per_step": round(pdt * 1e3, 3),
+                "bytes_per_step_over_pcie": int(px_host.nbytes), "gbs_over_pcie": round(px_host.nbytes / pdt / 1e9, 1),
+                "note": "the timed step with float32 pixel_values in pageable host memory (unpipelined: encode, then query); "
+                        "NOT `value`, which is measured with the inputs resident in HBM"}
+
     # ---------------------------------------------------------------- the same step with TWO batches in flight (N = 1 only)
     lanes = None
     if rank == 0 and world == 1 and not args.no_text:
@@ -723,7 +747,7 @@ def main():
             "encode_tflops": round(value * 8.298e9 / 1e12 / world, 1),
             "exactness": dict(index.guard_stats(), note="queries served by the step's index / of them not provable from the "
                               "first pass and widened (mmiss_index_guard_stats)"),
-            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest,
+            "roofline": roofline, "kernels": kernels, "retrieval": retrieval, "text": text, "single_request": latency, "ingest": ingest, "pcie_inclusive": pcie,
             "config1_self_index": config1, "two_batches_in_flight": lanes, "fp8_gemms": b32_fp8, "l14": l14,
             "cpu_baseline": cpu if world == 1 else {"see": "the N = 1 line of the same commit: the CPU baseline is timed on rank 0 "
                                                            "at N = 1 only (it needs the host cores the other ranks' launch threads use)"},
