@@ -16,6 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_one_rank_rccl_group_runs_the_sharded_query_and_the_bench_collectives():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["MASTER_ADDR"] = "127.0.0.1"
+    import socket
+
+    with socket.socket() as sk:   # a free rendezvous port (the tool's default is fixed)
+        sk.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(sk.getsockname()[1])
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1_rehearsal.py")], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
