@@ -142,7 +142,7 @@ def load() -> C.CDLL:
             raise ImportError("libmmiss.so ABI version mismatch")
         if (lib.mmiss_dbg_build_flags() & 2) and os.environ.get("MMISS_ALLOW_AB_BUILD") != "1":
             raise ImportError(
-                f"{LIB_PATH} was built with a timing-experiment macro (tools/*_ab.sh: P256_NO_LATE_WAIT, P256_SPLIT_STAGE, "
+                f"{LIB_PATH} was built with a timing-experiment macro (tools/*_ab.sh: P256_NO_LATE_WAIT, P256_SPLIT_STAGE, P256_STAGE_FIRST, "
                 "MMISS_SCAN_NT) and is not a product build; rebuild it (`make -C .../csrc clean all`) or set "
                 "MMISS_ALLOW_AB_BUILD=1 for the A/B run itself")
         _lib = lib

@@ -318,25 +318,37 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
 // sits in the read part of the phase BEFORE the one that reads it (both halves' waits and a barrier precede both halves'
 // reads); a slot is restaged in the phase AFTER its last read. P0 / P1 / P3 = post-epilogue form of the three waits; FIN =
 // this is K-tile 2 of a tile (the raw statistics landed behind the waits of K-tile 1).
+// P256_STAGE_FIRST (A/B experiment, tools/p256_stagefirst_ab.sh): a phase's two LDS-DMA pieces issued BEFORE its fragment
+// reads instead of behind them (they touch different slots: either order is correct)
+#ifdef P256_STAGE_FIRST
+#define P256_STAGE_A(...) P256_STAGE(__VA_ARGS__)
+#define P256_STAGE_B(...)
+#else
+#define P256_STAGE_A(...)
+#define P256_STAGE_B(...) P256_STAGE(__VA_ARGS__)
+#endif
 #define P256_KTILE(B, P0, P1, P3, FIN, HALF)                                                                       \
     {                                                                                                       \
+        P256_STAGE_A(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0);                                                 \
         P256_READ_A(B, 0);                                                                                  \
         P256_READ_W(B, 0);                                                                                  \
-        P256_STAGE(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0); /* A m1 of K-tile t+1 */                                          \
+        P256_STAGE_B(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0); /* A m1 of K-tile t+1 */                                          \
         P256_LATE_READS_DONE();                                                                             \
         P256_WAIT(P0, 0);                 /* retires W n1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
         P256_MMA(0, 0, P256_STAGE_MID(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0));                               \
         P256_BARRIER();                                                                                     \
+        P256_STAGE_A(0, B, oA2, oW2, true);                                                                 \
         P256_READ_W(B, 1);                                                                                  \
-        P256_STAGE(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                          \
+        P256_STAGE_B(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                          \
         P256_LATE_READS_DONE();                                                                             \
         P256_WAIT(P1, 1);                 /* retires A m1 of this K-tile */                                 \
         P256_BARRIER();                                                                                     \
         P256_MMA(0, 1, P256_STAGE_MID(0, B, oA2, oW2, true));                                               \
         P256_BARRIER();                                                                                     \
+        P256_STAGE_A(2, B, oA2, oW2, true);                                                                 \
         if constexpr (!(HALF)) { P256_READ_A(B, 1); }                                                       \
-        P256_STAGE(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
+        P256_STAGE_B(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
         P256_LATE_READS_DONE();                                                                             \
         P256_BARRIER();                                                                                     \
         if constexpr (!(HALF)) { P256_MMA(1, 1, P256_STAGE_MID(2, B, oA2, oW2, true)); }                    \
@@ -791,6 +803,8 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
 }
 
 #undef P256_STAGE
+#undef P256_STAGE_A
+#undef P256_STAGE_B
 #undef P256_STAGE_P
 #undef P256_STAGE_MID
 #undef P256_INFLIGHT

@@ -1,0 +1,14 @@
+set -u
+cd "$GRAFT_REPO_ROOT"
+# The variant is built IN PLACE (the tools load multimodal-image-similarity-search_amd/libmmiss.so); whatever happens, the product build is
+# restored on exit, and while the variant is in place mmiss_amd refuses to load it without MMISS_ALLOW_AB_BUILD=1.
+trap 'make -C multimodal-image-similarity-search_amd/csrc clean > /dev/null; make -C multimodal-image-similarity-search_amd/csrc -j16 > gpurun_out/ab_restore.log 2>&1 || tail -5 gpurun_out/ab_restore.log' EXIT
+export MMISS_ALLOW_AB_BUILD=1
+run() { for i in 1 2; do python tools/gemm_p256_probe.py; EPI=7 N=2304 python tools/gemm_p256_probe.py; M=4096 N=4096 K=4096 EPI=1 ITERS=20 python tools/gemm_p256_probe.py; done 2>&1 | grep -v amdgpu; }
+echo "== both pieces in the read part (default)"
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "p256" 2>&1 | tail -1
+run
+echo "== LDS-DMA pieces of a phase issued before its fragment reads"
+make -C multimodal-image-similarity-search_amd/csrc clean > /dev/null
+make -C multimodal-image-similarity-search_amd/csrc -j16 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable -DP256_STAGE_FIRST" > gpurun_out/ab_build.log 2>&1 || tail -5 gpurun_out/ab_build.log
+run
