@@ -137,10 +137,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     constexpr bool W8 = false;   // (the retrieval kernel below also takes fp8 index rows as its W operand)
     const int stage_dst = wave * 2048;
 #define P256_SLOT(which, b) (((which) * 2 + (b)) * G256_SLOT)
+// cache policy of the operand loads (the builtin's aux: 1 sc0, 2 nt, 16 sc1), per operand; A/B knobs of
+// tools/p256_policy_ab.sh (-DP256_A_POLICY=.. -DP256_W_POLICY=..), 0 = default in product builds
+#ifdef P256_A_POLICY
+#define P256_AUX_srdA P256_A_POLICY
+#else
+#define P256_AUX_srdA 0
+#endif
+#ifdef P256_W_POLICY
+#define P256_AUX_srdW P256_W_POLICY
+#else
+#define P256_AUX_srdW 0
+#endif
 #define P256_BLDS(srd, vo, so, dst) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 16, vo, so, 0, 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 16, vo, so, 0, P256_AUX_##srd)
 #define P256_BLDS4(srd, vo, so, dst) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 4, vo, so, 0, 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 4, vo, so, 0, P256_AUX_##srd)
 // LIVE = false: the slot is not read (the A m1 slot of a half tile): its two pieces shrink to 4 bytes per lane — the K
 // stream is bound by LDS-DMA bytes per CU (64 KB per K-tile at ~40 GB/s), the operation COUNT must stay what the waits assume
 // PCS: which of the slot's two 8-row pieces (bit 0 / bit 1)
@@ -811,6 +823,8 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
 #undef P256_MMA_HALF
 #undef P256_SLOT
 #undef P256_BLDS
+#undef P256_AUX_srdA
+#undef P256_AUX_srdW
 #undef P256_BLDS4
 #undef P256_READ_A
 #undef P256_READ_W
