@@ -59,7 +59,7 @@ struct mmiss_index {
     do { if ((ix)->pend.active) MM_FAIL(MMISS_ERR_STATE, "%s: a query begun with mmiss_index_query_begin is still open", who); } while (0)
 
 int mmiss_index_build_flags(void) {
-#if defined(P256_NO_LATE_WAIT) || defined(P256_SPLIT_STAGE) || defined(P256_STAGE_FIRST) || defined(P256_A_POLICY) || defined(P256_W_POLICY) || defined(MMISS_SCAN_NT)
+#if defined(P256_NO_LATE_WAIT) || defined(P256_SPLIT_STAGE) || defined(P256_STAGE_FIRST) || defined(P256_A_POLICY) || defined(P256_W_POLICY) || defined(P256_PRIO) || defined(MMISS_SCAN_NT)
     return 2;
 #else
     return 0;

@@ -288,6 +288,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                 acc[(nq) * 2 + nf][(mq) * 4 + mf] = MfmaIn<IN_T>::mma(                                      \
                     wq[nq][nf][s], am[mf][s], acc[(nq) * 2 + nf][(mq) * 4 + mf]);                           \
     }
+// wave priority inside / outside the MFMA part (A/B knob of tools/p256_prio_ab.sh: -DP256_PRIO=mma*4+rest; product 1 / 0)
+#ifdef P256_PRIO
+#define P256_PRIO_MMA ((P256_PRIO) / 4)
+#define P256_PRIO_REST ((P256_PRIO) % 4)
+#else
+#define P256_PRIO_MMA 1
+#define P256_PRIO_REST 0
+#endif
 // 16 MFMAs with MID (a slot's second LDS-DMA piece, or nothing) issued behind the first eight
 #define P256_MMA(mq, nq, MID)                                                                                \
     if constexpr ((DBG & 1) != 0) {                                                                         \
@@ -297,13 +305,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
             _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) asm volatile("" : "+v"(acc[(nq) * 2 + nf][(mq) * 4 + mf])); \
         MID;                                                                                                \
     } else {                                                                                                \
-        __builtin_amdgcn_s_setprio(1);                                                                      \
+        __builtin_amdgcn_s_setprio(P256_PRIO_MMA);                                                          \
         P256_MMA_HALF(mq, nq, 0)                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         MID;                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
         P256_MMA_HALF(mq, nq, 1)                                                                            \
-        __builtin_amdgcn_s_setprio(0);                                                                      \
+        __builtin_amdgcn_s_setprio(P256_PRIO_REST);                                                         \
     }
 // counted wait: P256_INFLIGHT = the pieces of the younger slot loads that stay in flight (four slots and a half: 9); POST = the stores and pieces of the
 // previous tile's epilogue are younger than the slot waited for
