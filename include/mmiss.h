@@ -43,14 +43,18 @@ enum {
     MMISS_ERR_IO = -6           /* file read/write failed (index save/load)          */
 };
 
-/* index storage dtypes. MMISS_F8: one byte per element, OCP e4m3 with the fixed scale 2^7 — a stored element is
- * decode(byte) / 128; a unit-norm row has |x_i| <= 1, so 128 x_i fits e4m3 and a typical component keeps its 3 mantissa bits.
- * Distances are exact (canonical fp64) with respect to the STORED rows, as for f16; the stored rows themselves are 2^-4-coarse
- * and are NOT renormalised after the rounding (|stored row| is within 3 % of 1), so what an fp8 index returns is
- * 1 - |stored| cos(query, stored), not a cosine distance: it ranks like the f32 / f16 index only up to that quantisation
- * (~1e-2 in cosine; rows closer together than that — e.g. one encoder's own embeddings — may swap, and a row need not rank
- * first for its own unquantised vector). Queries of any batch size take the streaming scan (half the bytes of f16 per row),
- * not the score-GEMM path. */
+/* index storage dtypes. MMISS_F8: one byte per element, OCP e4m3 with the fixed scale 2^7 — a code stands for the value
+ * decode(byte) / 128; a unit-norm row has |x_i| <= 1, so 128 x_i fits e4m3 and a typical component keeps its 3 mantissa
+ * bits — plus ONE float per row, the inverse of the canonical norm of the row's values (+0.8 % bytes at dim 512; derived from
+ * the codes, so save files do not hold it). The row the index REPRESENTS is values x inverse norm: a unit vector, so what an
+ * fp8 index returns is a cosine distance, 1 - cos(query, represented row) (the reference turns it into
+ * similarity = 1 - d / 2, backend/app/main.py:782, on that premise; round 4 returned 1 - |values| cos with |values| within
+ * 3 % of 1). Distances are exact (canonical fp64, x the inverse norm) with respect to the represented rows, as for f16; the
+ * represented rows themselves are 2^-4-coarse in every component: a row's direction lies within 1 - cos <= 4e-3 of the
+ * vector that was added, so an fp8 index ranks like the f32 / f16 index up to that (a row is found first by its own
+ * unquantised vector as long as its neighbours are further away than that; mmiss_index_get returns the represented rows).
+ * Up to 128 queries per call take the streaming scan (half the bytes of f16 per row), from 129 on the score GEMM with the
+ * codes widened to f16 in its operand load; both scale every score by the row's inverse norm. */
 enum { MMISS_F32 = 0, MMISS_F16 = 1, MMISS_F8 = 2 };
 
 typedef struct mmiss_encoder mmiss_encoder;
@@ -182,6 +186,8 @@ int mmiss_encoder_tap(mmiss_encoder* enc, int tower, int what, float* out, int64
 /* ---------------------------------------------------------------- flat index ------------------- */
 /*
  * Flat cosine index resident in HBM: rows are L2-normalised at add time and stored as f32, f16 or fp8 (e4m3).
+ * dim: a multiple of 128; f32 rows up to 1920, f16 / fp8 rows up to 3968 (the scan stages a 16-query block beside its
+ * lists in one CU's 160 KB of LDS) — anything else is MMISS_ERR_UNSUPPORTED here, not a failed launch at the first query.
  * replaces chromadb's collection with metadata {"hnsw:space":"cosine"} — backend/app/utils.py:104-137
  */
 int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device, int64_t capacity_hint, mmiss_index** out);

@@ -135,6 +135,14 @@ class FlatCollection:
     def _replay_journal(self) -> None:
         jl, jv = self._journal_paths(self._index_gen)
         if not os.path.exists(jl):
+            # No commit line exists in this generation. A crash inside the FIRST journaled mutation's vector write still leaves
+            # bytes in the vector file that no record owns: drop them, or the next add records an offset behind (or inside)
+            # them and the restart after that one cuts the whole log back to nothing.
+            if os.path.exists(jv) and os.path.getsize(jv) > 0:
+                with open(jv, "r+b") as f:
+                    f.truncate(0)
+                    f.flush()
+                    os.fsync(f.fileno())
             return
         # The vector file may end in a torn write (a crash inside f.write of the vectors — the large write, so the likelier one
         # to tear): its size need not be a multiple of 4. Map only the whole floats; the tail is cut off below.

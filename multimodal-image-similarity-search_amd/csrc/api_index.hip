@@ -19,6 +19,7 @@ struct mmiss_index {
     std::mutex mu;
     int64_t count = 0, capacity = 0;
     DevBuf rows, labels_d;
+    DevBuf inv;   // MMISS_F8 only: [capacity] f32, inverse norm of every row's values (f8_row_inv_kernel); zero behind count
     std::vector<int64_t> labels_h;
     // scratch
     DevBuf stage, qn, qs, qstage, lists_s, lists_r, lists2_s, lists2_r, cand, cur_s, cur_r, out_c, map, gmax;
@@ -72,29 +73,48 @@ int index_reserve(mmiss_index* ix, int64_t need, hipStream_t st) {
     if (need <= ix->capacity) return MMISS_OK;
     int64_t cap = ix->capacity > 0 ? ix->capacity : 1024;
     while (cap < need) cap *= 2;
-    DevBuf nr, nl;
+    DevBuf nr, nl, ni;
     MM_TRY(nr.alloc((size_t)cap * ix->dim * ix->elt));
     MM_TRY(nl.alloc((size_t)cap * 8));
+    if (ix->dtype == MMISS_F8) {
+        // zero behind the rows: the score GEMM reads the inverse norms of a whole 256-row tile, the scan of a 16-row one
+        MM_TRY(ni.alloc((size_t)cap * 4));
+        MM_HIP(hipMemsetAsync(ni.p, 0, (size_t)cap * 4, st));
+    }
     if (ix->count > 0) {
         MM_HIP(hipMemcpyAsync(nr.p, ix->rows.p, (size_t)ix->count * ix->dim * ix->elt, hipMemcpyDeviceToDevice, st));
         MM_HIP(hipMemcpyAsync(nl.p, ix->labels_d.p, (size_t)ix->count * 8, hipMemcpyDeviceToDevice, st));
-        MM_HIP(hipStreamSynchronize(st));
+        if (ni.p) MM_HIP(hipMemcpyAsync(ni.p, ix->inv.p, (size_t)ix->count * 4, hipMemcpyDeviceToDevice, st));
     }
+    MM_HIP(hipStreamSynchronize(st));
     std::swap(ix->rows.p, nr.p); std::swap(ix->rows.bytes, nr.bytes);
     std::swap(ix->labels_d.p, nl.p); std::swap(ix->labels_d.bytes, nl.bytes);
+    std::swap(ix->inv.p, ni.p); std::swap(ix->inv.bytes, ni.bytes);
     ix->capacity = cap;
     return MMISS_OK;
 }
 
-int launch_normalize(mmiss_index* ix, const float* src_dev, void* dst, int64_t n, hipStream_t st) {
+// the inverse norms of fp8 rows [row0, row0 + n) from their codes (after every write of rows: add, update, load)
+int launch_f8_inv(mmiss_index* ix, int64_t row0, int64_t n, hipStream_t st) {
+    if (n <= 0 || ix->dtype != MMISS_F8) return MMISS_OK;
+    hipLaunchKernelGGL(f8_row_inv_kernel, dim3((int)((n + 3) / 4)), dim3(256), 0, st, ix->rows.as<uint8_t>() + (size_t)row0 * ix->dim, n,
+                       ix->dim, ix->inv.as<float>() + row0);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+// `row0`: the index row dst stands for (fp8 rows: where the inverse norms go)
+int launch_normalize(mmiss_index* ix, const float* src_dev, void* dst, int64_t n, hipStream_t st, int64_t row0) {
     if (n <= 0) return MMISS_OK;
     MM_PROF("normalize_rows", st, 4.0 * n * ix->dim, (double)n * ix->dim * (4 + ix->elt));
     const int grid = (int)((n + 3) / 4);
     if (ix->dtype == MMISS_F16)
         hipLaunchKernelGGL(normalize_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, src_dev, (_Float16*)dst, n, ix->dim);
-    else if (ix->dtype == MMISS_F8)
+    else if (ix->dtype == MMISS_F8) {
         hipLaunchKernelGGL(normalize_rows_kernel<F8>, dim3(grid), dim3(256), 0, st, src_dev, (F8*)dst, n, ix->dim);
-    else
+        MM_HIP(hipGetLastError());
+        return launch_f8_inv(ix, row0, n, st);
+    } else
         hipLaunchKernelGGL(normalize_rows_kernel<float>, dim3(grid), dim3(256), 0, st, src_dev, (float*)dst, n, ix->dim);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
@@ -137,9 +157,19 @@ struct ScanPlan {
     int nqt, cap, lds, slabs, qtiles, tiles_per_block;
 };
 
+constexpr int SCAN_LDS_LIMIT = 160 * 1024;
+// dynamic LDS of the streaming scan for a block of 16 * nqt queries: the staged query rows (+ 16 B of padding each) and,
+// in list mode, four waves' (score, row) lists of `cap` entries per query with their counts and thresholds
+int scan_lds_bytes(int D, int qelt, int nqt, int cap) {
+    const int NQ = 16 * nqt;
+    return (((NQ * (D * qelt + 16)) + 15) & ~15) + 2 * 4 * NQ * cap * 4 + 2 * 4 * NQ * 4;
+}
+// ... in threshold mode (the widen pass): the query rows only
+int sweep_scan_lds(int D, int qelt, int nqt) { return ((16 * nqt * (D * qelt + 16)) + 15) & ~15; }
+
 ScanPlan plan_scan(int D, int elt, int Q, int kp, int64_t N) {
     ScanPlan p{};
-    const int limit = 160 * 1024;
+    const int limit = SCAN_LDS_LIMIT;
     p.nqt = 1; p.cap = 64;
     if (kp <= 16 && Q > 16) {
         for (int nqt : {4, 2}) {
@@ -220,6 +250,12 @@ extern "C" int mmiss_index_create(int32_t dim, int32_t storage_dtype, int device
     if (dim <= 0 || dim % 128 || dim > 4096) MM_FAIL(MMISS_ERR_UNSUPPORTED, "index dim %d: need a multiple of 128, <= 4096", dim);
     if (storage_dtype != MMISS_F32 && storage_dtype != MMISS_F16 && storage_dtype != MMISS_F8)
         MM_FAIL(MMISS_ERR_ARG, "unknown storage dtype %d", storage_dtype);
+    // the streaming scan stages 16 queries in the storage's query dtype (f32 rows: f32 queries) beside its lists: f32 rows
+    // fit up to dim 1920, f16 / fp8 rows up to 3968 (a create-time answer instead of a failed launch at the first query)
+    if (scan_lds_bytes(dim, storage_dtype == MMISS_F32 ? 4 : 2, 1, 64) > SCAN_LDS_LIMIT)
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "index dim %d with storage dtype %d: a 16-query block of the scan needs %d bytes of LDS (limit %d); "
+                "f32 rows go up to dim 1920, f16 / fp8 rows up to 3968", dim, storage_dtype,
+                scan_lds_bytes(dim, storage_dtype == MMISS_F32 ? 4 : 2, 1, 64), SCAN_LDS_LIMIT);
     MM_TRY(mmiss_use_device(device));
     mmiss_index* ix = new (std::nothrow) mmiss_index();
     if (!ix) MM_FAIL(MMISS_ERR_NOMEM, "out of host memory");
@@ -286,6 +322,11 @@ extern "C" int mmiss_index_clear(mmiss_index* ix) {
     if (!ix) MM_FAIL(MMISS_ERR_ARG, "null index");
     std::lock_guard<std::mutex> lk(ix->mu);
     MM_NO_PENDING(ix, "mmiss_index_clear");
+    if (ix->dtype == MMISS_F8 && ix->capacity > 0) {   // (inverse norms are zero behind the rows)
+        MM_TRY(mmiss_use_device(ix->device));
+        MM_HIP(hipMemsetAsync(ix->inv.p, 0, (size_t)ix->capacity * 4, ix->stream()));
+        MM_HIP(hipStreamSynchronize(ix->stream()));
+    }
     ix->count = 0;
     ix->labels_h.clear();
     return MMISS_OK;
@@ -323,7 +364,7 @@ extern "C" int mmiss_index_add(mmiss_index* ix, const float* vecs, const int64_t
             MM_HIP(hipMemcpyAsync(ix->stage.p, src, (size_t)nr * D * 4, hipMemcpyHostToDevice, st));
             src = ix->stage.as<float>();
         }
-        MM_TRY(launch_normalize(ix, src, ix->rows.as<char>() + (size_t)(ix->count + r0) * D * ix->elt, nr, st));
+        MM_TRY(launch_normalize(ix, src, ix->rows.as<char>() + (size_t)(ix->count + r0) * D * ix->elt, nr, st, ix->count + r0));
         if (!in_dev) MM_HIP(hipStreamSynchronize(st));
     }
     MM_HIP(hipMemcpyAsync(ix->labels_d.as<int64_t>() + ix->count, lab.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
@@ -355,7 +396,7 @@ extern "C" int mmiss_index_update(mmiss_index* ix, const int64_t* labels, const 
         src = ix->stage.as<float>();
     }
     for (int64_t i = 0; i < n; ++i)
-        MM_TRY(launch_normalize(ix, src + i * D, ix->rows.as<char>() + (size_t)rows[i] * D * ix->elt, 1, st));
+        MM_TRY(launch_normalize(ix, src + i * D, ix->rows.as<char>() + (size_t)rows[i] * D * ix->elt, 1, st, rows[i]));
     MM_HIP(hipStreamSynchronize(st));
     return MMISS_OK;
 }
@@ -384,19 +425,25 @@ extern "C" int mmiss_index_remove(mmiss_index* ix, const int64_t* labels, int64_
         if (!drop[r]) { map[o] = r; nl[o] = ix->labels_h[r]; ++o; }
     if (keep > 0) {
         // stable compaction into fresh buffers (row order == label order is the tie-break contract)
-        DevBuf nr, nlab;
+        DevBuf nr, nlab, ninv;
         MM_TRY(nr.alloc((size_t)ix->capacity * ix->dim * ix->elt));
         MM_TRY(nlab.alloc((size_t)ix->capacity * 8));
+        if (ix->dtype == MMISS_F8) {
+            MM_TRY(ninv.alloc((size_t)ix->capacity * 4));
+            MM_HIP(hipMemsetAsync(ninv.p, 0, (size_t)ix->capacity * 4, st));
+        }
         MM_TRY(ix->map.ensure((size_t)keep * 8));
         MM_HIP(hipMemcpyAsync(ix->map.p, map.data(), (size_t)keep * 8, hipMemcpyHostToDevice, st));
         const int grid = (int)std::min<int64_t>(4096, (keep * ix->dim + 255) / 256);
         if (ix->dtype == MMISS_F16)
             hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.as<_Float16>(),
                                ix->map.as<int64_t>(), nr.as<_Float16>(), keep, ix->dim);
-        else if (ix->dtype == MMISS_F8)
+        else if (ix->dtype == MMISS_F8) {
             hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, ix->rows.as<uint8_t>(),
                                ix->map.as<int64_t>(), nr.as<uint8_t>(), keep, ix->dim);
-        else
+            hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((int)std::min<int64_t>(4096, (keep + 255) / 256)), dim3(256), 0, st,
+                               ix->inv.as<float>(), ix->map.as<int64_t>(), ninv.as<float>(), keep, 1);
+        } else
             hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.as<float>(),
                                ix->map.as<int64_t>(), nr.as<float>(), keep, ix->dim);
         MM_HIP(hipGetLastError());
@@ -404,6 +451,7 @@ extern "C" int mmiss_index_remove(mmiss_index* ix, const int64_t* labels, int64_
         MM_HIP(hipStreamSynchronize(st));
         std::swap(ix->rows.p, nr.p); std::swap(ix->rows.bytes, nr.bytes);
         std::swap(ix->labels_d.p, nlab.p); std::swap(ix->labels_d.bytes, nlab.bytes);
+        std::swap(ix->inv.p, ninv.p); std::swap(ix->inv.bytes, ninv.bytes);
     }
     ix->labels_h.swap(nl);
     ix->count = keep;
@@ -433,8 +481,8 @@ extern "C" int mmiss_index_get(mmiss_index* ix, const int64_t* labels, int64_t n
     if (ix->dtype == MMISS_F16)
         hipLaunchKernelGGL(gather_rows_f32_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.as<_Float16>(),
                            ix->map.as<int64_t>(), dst, n, ix->dim);
-    else if (ix->dtype == MMISS_F8)
-        hipLaunchKernelGGL(gather_rows_f32_kernel<F8>, dim3(grid), dim3(256), 0, st, ix->rows.as<F8>(),
+    else if (ix->dtype == MMISS_F8)   // the vectors the rows represent: values x inverse norm
+        hipLaunchKernelGGL(gather_rows_f8_f32_kernel, dim3(grid), dim3(256), 0, st, ix->rows.as<F8>(), ix->inv.as<float>(),
                            ix->map.as<int64_t>(), dst, n, ix->dim);
     else
         hipLaunchKernelGGL(gather_rows_f32_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.as<float>(),
@@ -481,9 +529,12 @@ constexpr int SWEEP_CAP = 8192;   // rows a widened query may collect (= the re-
 //   the float rounding of the canonical distance (<= 2) is 2^-23 at most.
 void guard_terms(const mmiss_index* ix, double* fixed, double* cnorm) {
     const double D = ix->dim;
+    // (fp8 rows: |values| x inv = 1 up to inv's own rounding; 1.07 is kept from the un-renormalised form of round 4 — it only
+    // widens the bound — and the scan's multiplication by inv adds one more f32 rounding of a score <= 1.08)
     const double cn = ix->dtype == MMISS_F8 ? 1.07 : 1.0 + ldexp(1.0, -9);
     double e = 4.0 * D * ldexp(1.0, -24) * cn * (1.0 + ldexp(1.0, -9));
-    if (ix->dtype != MMISS_F32) e += D * ldexp(1.0, -25);
+    if (ix->dtype != MMISS_F32) e += D * ldexp(1.0, -25) * cn;
+    if (ix->dtype == MMISS_F8) e += ldexp(1.0, -23);
     *fixed = e * 1.003 + ldexp(1.0, -21);
     *cnorm = ix->dtype == MMISS_F32 ? 0.0 : cn * 1.003;
 }
@@ -536,13 +587,13 @@ int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_
             const int grid = (int)std::min<int64_t>(8192, (N + 15) / 16);
             if (ix->dtype == MMISS_F16)
                 hipLaunchKernelGGL(canonical_scan_kernel<_Float16>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
-                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
+                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>(), (const float*)nullptr);
             else if (ix->dtype == MMISS_F8)
                 hipLaunchKernelGGL(canonical_scan_kernel<F8>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
-                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
+                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>(), (const float*)ix->inv.as<float>());
             else
                 hipLaunchKernelGGL(canonical_scan_kernel<float>, dim3(grid), dim3(256), 0, st, ix->rows.p, N, D,
-                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>());
+                                   ix->qn.as<float>() + (size_t)q * D, ix->dist_all.as<float>(), (const float*)nullptr);
             MM_HIP(hipGetLastError());
         }
         MM_HIP(hipMemcpyAsync(ix->dist_pin, ix->dist_all.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
@@ -564,7 +615,7 @@ int exhaustive_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_
     MM_HIP(hipMemcpyAsync(ix->cand2.p, cand.data(), (size_t)nq * kkpad * 4, hipMemcpyHostToDevice, st));
     MM_HIP(hipMemcpyAsync(ix->qmap.p, which.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
     RerankArgs r{};
-    r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand2.as<int32_t>();
+    r.rows = ix->rows.p; r.D = D; r.inv = ix->inv.as<float>(); r.qn = ix->qn.as<float>(); r.cand = ix->cand2.as<int32_t>();
     r.cand_stride = kkpad; r.ncand = kkpad; r.group_mode = 0; r.nrows = N;
     r.labels = ix->labels_d.as<int64_t>(); r.k = k;
     r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
@@ -649,6 +700,7 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
         const int64_t Npad = round_up(N, 256), nbn = Npad / 256;
         GemmEpi ep{};
         ep.m_valid = Qf; ep.p0 = (int)N; ep.m_fast = 1;
+        ep.aux = ix->inv.as<float>();   // (fp8 rows: inverse norms; null otherwise)
         StripFilter flt{};
         flt.tau = thr_sw; flt.tau_stride = 1; flt.cnt = ix->swp_cnt.as<int32_t>();
         flt.buf_s = nullptr; flt.buf_g = ix->swp_list.as<int32_t>(); flt.cap = SWEEP_CAP; flt.bn_begin = 0;
@@ -659,14 +711,20 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
         ix->stat_pages += 1;
     } else {
         ScanArgs a{};
-        a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = qs_sw; a.Q = Qf;
+        a.rows = ix->rows.p; a.N = N; a.D = D; a.inv = ix->inv.as<float>(); a.qs = qs_sw; a.Q = Qf;
         a.thr = thr_sw; a.gcnt = ix->swp_cnt.as<int32_t>(); a.glist = ix->swp_list.as<int32_t>(); a.gcap = SWEEP_CAP;
-        const int nqt = Qf > 32 ? 4 : Qf > 16 ? 2 : 1;
+        // the widest query tile the flagged queries fill AND whose staged query block fits the CU's LDS (f32 rows at the
+        // reference's D = 768: 64 queries x 3088 B = 193 KB do not, 32 do). nqt = 1 always fits: mmiss_index_create
+        // admits only dims whose 16-query block does.
+        int nqt = Qf > 32 ? 4 : Qf > 16 ? 2 : 1;
+        while (nqt > 1 && sweep_scan_lds(D, ix->qelt(), nqt) > SCAN_LDS_LIMIT) nqt >>= 1;
         const int NQ = 16 * nqt;
-        const int lds = ((NQ * (D * ix->qelt() + 16)) + 15) & ~15;
+        const int lds = sweep_scan_lds(D, ix->qelt(), nqt);
+        if (lds > SCAN_LDS_LIMIT)
+            MM_FAIL(MMISS_ERR_UNSUPPORTED, "widen pass: a 16-query block of dim %d does not fit the LDS (%d bytes)", D, lds);
         const int qtiles = (Qf + NQ - 1) / NQ;
         const int64_t ntiles = (N + 15) / 16;
-        const int per_cu = std::max(1, std::min(8, 160 * 1024 / lds));
+        const int per_cu = std::max(1, std::min(8, SCAN_LDS_LIMIT / lds));
         int64_t target = std::max<int64_t>(1, (int64_t)256 * per_cu / qtiles);
         int64_t tpb = std::max<int64_t>(4, (((ntiles + target - 1) / target) + 3) / 4 * 4);
         a.tiles_per_block = (int)tpb;
@@ -694,7 +752,7 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
     // exhaustive pass.
     const int SWEEP_FAST = 1024;
     RerankArgs r{};
-    r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->swp_list.as<int32_t>();
+    r.rows = ix->rows.p; r.D = D; r.inv = ix->inv.as<float>(); r.qn = ix->qn.as<float>(); r.cand = ix->swp_list.as<int32_t>();
     r.cand_stride = SWEEP_CAP; r.ncand = SWEEP_FAST; r.cand_cnt = ix->swp_cnt.as<int32_t>();
     r.group_mode = 0; r.nrows = N;
     r.labels = ix->labels_d.as<int64_t>(); r.k = k;
@@ -840,6 +898,7 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         MM_TRY(ix->gmax.ensure((size_t)Mq * ng * 4));
         GemmEpi ep{};
         ep.out = ix->gmax.p; ep.ldo = ng; ep.m_valid = Q; ep.p0 = (int)N; ep.m_fast = 1;
+        ep.aux = ix->inv.as<float>();   // (fp8 rows: inverse norms; null otherwise)
         int strip = 1;
         // the strip kernel on the staggered loop of the persistent encoder GEMM (gemm_bf16_p256.h; round 3): D % 128 == 0
         const bool strip_v3 = mmiss_option("score_strip_v3", 1) != 0 && (D % 128) == 0 && D >= 256;
@@ -922,7 +981,7 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
         }
         for (int page = 0; page < pages; ++page) {
             ScanArgs a{};
-            a.rows = ix->rows.p; a.N = N; a.D = D; a.qs = ix->qs.p; a.Q = Q;
+            a.rows = ix->rows.p; a.N = N; a.D = D; a.inv = ix->inv.as<float>(); a.qs = ix->qs.p; a.Q = Q;
             a.cur_s = paging ? ix->cur_s.as<float>() : nullptr;
             a.cur_r = paging ? ix->cur_r.as<int32_t>() : nullptr;
             a.kp = kp; a.tiles_per_block = p.tiles_per_block;
@@ -938,7 +997,7 @@ int query_begin_locked(mmiss_index* ix, const float* queries, int32_t Q, int32_t
     }
     {
         RerankArgs r{};
-        r.rows = ix->rows.p; r.D = D; r.qn = ix->qn.as<float>(); r.cand = ix->cand.as<int32_t>();
+        r.rows = ix->rows.p; r.D = D; r.inv = ix->inv.as<float>(); r.qn = ix->qn.as<float>(); r.cand = ix->cand.as<int32_t>();
         r.cand_stride = ncand; r.ncand = dense ? ncand * 16 : ncand; r.group_mode = dense ? 1 : 0; r.nrows = N;
         r.labels = ix->labels_d.as<int64_t>(); r.k = k;
         r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
@@ -1125,6 +1184,12 @@ extern "C" int mmiss_index_load(mmiss_index* ix, const char* path) {
     if (rc != MMISS_OK) return rc;
     if (!ok) MM_FAIL(MMISS_ERR_IO, "%s is truncated or corrupt", path);
     if (h.count) MM_HIP(hipMemcpy(ix->labels_d.p, lab.data(), (size_t)h.count * 8, hipMemcpyHostToDevice));
+    // fp8 rows: the file holds the codes only; their inverse norms are a function of the codes (files of round 4 load as they are)
+    if (ix->dtype == MMISS_F8 && ix->capacity > 0) {
+        MM_HIP(hipMemsetAsync(ix->inv.p, 0, (size_t)ix->capacity * 4, st));
+        MM_TRY(launch_f8_inv(ix, 0, h.count, st));
+        MM_HIP(hipStreamSynchronize(st));
+    }
     ix->labels_h.swap(lab);
     ix->count = h.count;
     return MMISS_OK;

@@ -588,7 +588,14 @@ __global__ __launch_bounds__(512) void attention_long_kernel(const uint16_t* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int dmodel = H * 64, ld = 3 * dmodel;
     const int fr = lane & 15, fg = lane >> 4;
-    const int nqt = (dbg & 2) ? 0 : (T + 15) >> 4;   // (dbg: timing ablations, option att_dbg — 1 = no K/V loads, 2 = no query tiles)
+    // dbg: timing ablations of tools/attention_l14_ablate.py (1 = no K/V loads, 2 = no query tiles; results wrong by
+    // construction) — compiled into EXPERIMENTS builds only, a product build ignores the argument
+#ifdef MMISS_EXPERIMENTS
+    const int dbg_e = dbg;
+#else
+    constexpr int dbg_e = 0;
+#endif
+    const int nqt = (dbg_e & 2) ? 0 : (T + 15) >> 4;
     const float c_exp = 0.125f * 1.4426950408889634f;
     const float thr_raw = 8.0f / c_exp;              // deferred rescale: the offset may lag the maximum by 8 binary orders
     // per-lane constants of the LDS addresses (krow & 7 = fr & 7: a key tile starts at a multiple of 16 rows)
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(512) void attention_long_kernel(const uint16_t* __r
     for (int idx = tid; idx < TP * 8; idx += NW * 64) {
         const int row = idx >> 3, c = idx & 7;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (row < T && !(dbg & 1)) {
+        if (row < T && !(dbg_e & 1)) {
             kv = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + dmodel + c * 8);
             vv = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + 2 * dmodel + c * 8);
         }
@@ -909,7 +916,12 @@ static int launch_attention_long_t(hipStream_t st, const void* qkv, void* ctx, u
     qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_long_kernel<NKP, CAUSAL, MXOUT>), lds));
     hipLaunchKernelGGL((attention_long_kernel<NKP, CAUSAL, MXOUT>), dim3(items, qs), dim3(512), lds, st, (const uint16_t*)qkv,
-                       (uint16_t*)ctx, T, H, ctx8, ctxs, ld_s, mmiss_option("att_dbg", 0));
+                       (uint16_t*)ctx, T, H, ctx8, ctxs, ld_s,
+#ifdef MMISS_EXPERIMENTS
+                       mmiss_option("att_dbg", 0));
+#else
+                       0);
+#endif
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }

@@ -644,7 +644,13 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     constexpr int DBG = 0;
     uint32_t ab32[4], wb32[4]; f32x16 acc32[2][4];   // (named by the loop macros' DBG & 128 branches only: never touched here)
     constexpr bool FOLD = false;
-    constexpr int EX = 0;
+    // fp8 rows carry one inverse norm each (ep.aux, f8_row_inv_kernel): the 64 of a wave's column quarter arrive by a 4-byte
+    // LDS-DMA piece per wave into the wave's private 256 bytes behind the staging slots. The piece is issued at the head of
+    // EVERY K-tile pair (the current index tile's values again: 256 bytes per wave), so that the operation counts of the
+    // waits are the same in every pair — the four waits behind a piece allow for one more operation in flight (the POST
+    // form of the waits, EX = 1), the fifth retires it. (Issued once per tile between the K streams, with plain and POST
+    // pairs side by side in the loop as in gemm256p_kernel, this kernel spilled 270 registers.)
+    constexpr int EX = W8 ? 1 : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -706,6 +712,13 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
 
     int oA1 = 0, oW1 = 0, oA2 = GEMM_BK * (int)sizeof(IN), oW2 = GEMM_BK * WELT;
     int o2 = 0, k2 = 1;
+    auto stage_inv = [&](int ti_) {   // the inverse norms of index tile bn0 + ti_, this wave's 64 rows (both halves load their copy)
+        if constexpr (W8) {
+            const float* src = ep.aux + (size_t)(bn0 + ti_) * 256 + wn * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + G256_LDS + wave * 256), 4, 0, 0);
+        }
+    };
     {
         char* d0 = smem + stage_dst;
         // (the same operations per slot and wave as in the loop, in the same order: the counted waits depend on it)
@@ -738,8 +751,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
     float* out = reinterpret_cast<float*>(ep.out);
     for (int ti = 0; ti < mine; ++ti) {
         for (int kp = 0; kp < npair; ++kp) {
-            P256_KTILE(0, false, false, false, false, false);
-            P256_KTILE(1, false, false, false, false, false);
+            stage_inv(ti);   // (W8; younger than the slots the next four waits retire, older than what the fifth retires)
+            P256_KTILE(0, W8, W8, W8, false, false);
+            P256_KTILE(1, W8, false, false, false, false);
         }
         // ---- this index tile is complete: group maxima out (the group numbering of gemm256_kernel), accumulators reset.
         // A few hundred cycles of VALU: it runs without leaving the staggered rhythm (each half does it in front of its next
@@ -750,6 +764,17 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
         const bool whole = (bn + 1) * 256 <= ep.p0;
         asm volatile("s_nop 11" ::: "memory");   // the asm maxima below read the accumulators of the tile's last MFMAs (mm_mfma_settle)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (W8) {
+            // scores of fp8 rows: x inv[row] (this wave's own piece: the one issued at the head of the tile's first pair landed
+            // behind that pair's fifth wait, later ones rewrite the same bytes)
+            const char* ivp = smem + G256_LDS + wave * 256 + fg * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 iv = *reinterpret_cast<const f32x4*>(ivp + i * 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = acc[i][j] * iv;
+            }
+        }
         if constexpr (FILTER == 2) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -924,24 +949,26 @@ static int launch_gemm256s(hipStream_t st, const void* A, const void* W, const G
         (int64_t)strip * 256 * K * (int64_t)sizeof(IN) >= (1LL << 31) || (int64_t)256 * K * (int64_t)sizeof(IN) >= (1LL << 31))
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256s: M=%d N=%d K=%d strip=%d", M, N, K, strip);
     const int nbn = N / 256;
+    if (W8 && !ep.aux) MM_FAIL(MMISS_ERR_ARG, "gemm256s: fp8 rows need their inverse norms (ep.aux)");
+    const int lds = G256_LDS + (W8 ? 2048 : 0);   // + 8 waves x 64 inverse norms
     if (flt) {
         const bool rows_mode = flt->buf_s == nullptr;   // (the row threshold pass keeps no scores)
         if (flt->bn_begin < 0 || flt->bn_begin >= nbn || !flt->tau || !flt->cnt || !flt->buf_g || flt->cap <= 0)
             MM_FAIL(MMISS_ERR_ARG, "gemm256s: bad filter");
         const int nwg = (M / 256) * ((nbn - flt->bn_begin + strip - 1) / strip);
         if (rows_mode) {
-            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 2, W8>), G256_LDS));
-            hipLaunchKernelGGL((gemm256s_kernel<IN, 2, W8>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 2, W8>), lds));
+            hipLaunchKernelGGL((gemm256s_kernel<IN, 2, W8>), dim3(nwg), dim3(512), lds, st, reinterpret_cast<const IN*>(A),
                                W, M, N, K, strip, ep, *flt);
         } else {
-            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 1, W8>), G256_LDS));
-            hipLaunchKernelGGL((gemm256s_kernel<IN, 1, W8>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+            MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 1, W8>), lds));
+            hipLaunchKernelGGL((gemm256s_kernel<IN, 1, W8>), dim3(nwg), dim3(512), lds, st, reinterpret_cast<const IN*>(A),
                                W, M, N, K, strip, ep, *flt);
         }
     } else {
-        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 0, W8>), G256_LDS));
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256s_kernel<IN, 0, W8>), lds));
         const int nwg = (M / 256) * ((nbn + strip - 1) / strip);
-        hipLaunchKernelGGL((gemm256s_kernel<IN, 0, W8>), dim3(nwg), dim3(512), G256_LDS, st, reinterpret_cast<const IN*>(A),
+        hipLaunchKernelGGL((gemm256s_kernel<IN, 0, W8>), dim3(nwg), dim3(512), lds, st, reinterpret_cast<const IN*>(A),
                            W, M, N, K, strip, ep, StripFilter{});
     }
     MM_HIP(hipGetLastError());

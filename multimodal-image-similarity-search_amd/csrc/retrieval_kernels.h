@@ -73,6 +73,25 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     }
 }
 
+// MMISS_F8 rows: the e4m3 rounding moves a row's norm by up to ~3 %, so the codes alone would give 1 - |stored| cos instead of
+// a cosine distance (round 4). Every fp8 row therefore carries ONE float: inv[r] = float(1 / canonical norm of the values its
+// codes stand for). The row the index represents is values * inv (unit norm up to that one rounding); every score — the
+// scan's, the score GEMM's, the canonical re-rank's — is the dot product with the codes' values TIMES inv[r]. One wave per
+// row; recomputed from the codes wherever rows are (re)written, so the save file does not hold it.
+__global__ __launch_bounds__(256) void f8_row_inv_kernel(const uint8_t* __restrict__ codes, int64_t n, int D, float* __restrict__ inv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const uint8_t* c = codes + r * D;
+    double acc = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const double v = (double)(__builtin_amdgcn_cvt_f32_fp8((int)c[d], 0) * (1.0f / MMISS_F8_SCALE));
+        acc = acc + v * v;
+    }
+    const double nrm = sqrt(wave_butterfly_sum(acc));
+    if (lane == 0) inv[r] = (float)(1.0 / nrm);
+}
+
 // Query preparation: qn = canonical normalisation (f32, used by the rerank), qs = qn in the storage
 // dtype for the scan's MFMA operand, rows [Q, Qpad) zero-filled.
 // eps_q (optional): the exactness guard's per-query bound on |approximate - canonical| score (api_index.hip, "exactness
@@ -203,6 +222,7 @@ struct ScanArgs {
     int32_t* gcnt;        // [Q]
     int32_t* glist;       // [Q][gcap]
     int gcap;
+    const float* inv;     // fp8 rows: [>= N rounded up to 16] inverse norm of every row's values (f8_row_inv_kernel); scores are x inv
 };
 
 template <int NQT, int CAP>
@@ -307,6 +327,9 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
         f32x4 acc[NQT];
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // fp8 rows: what each of this lane's four rows (row0 + 4 fg + reg) is scaled by — issued with the tile's row loads
+        f32x4 rinv = {ScanTraits<T>::SCORE_SCALE, ScanTraits<T>::SCORE_SCALE, ScanTraits<T>::SCORE_SCALE, ScanTraits<T>::SCORE_SCALE};
+        if constexpr (ELT == 1) rinv = *reinterpret_cast<const f32x4*>(a.inv + row0 + 4 * fg) * ScanTraits<T>::SCORE_SCALE;
         // f16 / f32 rows: 64 bytes of every row per step (4 lanes x 16 B: 32 f16 or 16 f32 elements of k); steps are issued
         // in groups of 8 (then 4) with all the group's global loads ahead of its MFMAs, so 8 (4) 1-KiB wave-loads are in
         // flight per wave
@@ -388,7 +411,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int64_t row = row0 + 4 * fg + reg;
-                    const float s = acc[qt][reg] * ScanTraits<T>::SCORE_SCALE;
+                    const float s = acc[qt][reg] * rinv[reg];
                     if (q < a.Q && row < a.N && s >= tau_r[qt]) {
                         const int pos = atomicAdd(a.gcnt + q, 1);
                         if (pos < a.gcap) a.glist[(size_t)q * a.gcap + pos] = (int)row;
@@ -406,7 +429,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(ScanArgs a) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int64_t row = row0 + 4 * fg + reg;
-                const float s = acc[qt][reg] * ScanTraits<T>::SCORE_SCALE;   // (a power of two: exact)
+                const float s = acc[qt][reg] * rinv[reg];   // (f16 / f32 rows: x 1; fp8 rows: x inv[row] / 128, one rounding)
                 const int ri = (int)row;
                 const bool after = (s < cur_s[qt]) || (s == cur_s[qt] && ri > cur_r[qt]);
                 if (qok && row < a.N && s > tau_r[qt] && after) {
@@ -741,6 +764,7 @@ struct RerankArgs {
     float* thr_out;
     const int32_t* cand_cnt;  // per-block candidate count (widen pass: the appended rows), null: ncand for every block
     const int32_t* bmap;      // block b reads candidate list / count bmap[b] (null: b)
+    const float* inv;         // fp8 rows: inverse norm per row (f8_row_inv_kernel): canonical score = canon_dot x (double)inv[row]
 };
 
 // The four partial sums of one lane of the canonical dot product (lane p of a row's 16: elements d = 4p + j + 64 i, i
@@ -836,8 +860,9 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
             for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __shfl_xor(acc[j], o);
         }
         const double t0 = acc[0] + acc[2], t1 = acc[1] + acc[3];
-        const double dot = t0 + t1;
+        double dot = t0 + t1;
         if (p16 == 0 && row >= 0) {
+            if constexpr (sizeof(T) == 1) dot = dot * (double)a.inv[row];   // fp8 rows: the represented row is values x inv
             sd[c] = (float)(1.0 - dot);
             sr[c] = (int32_t)row;
         }
@@ -914,7 +939,8 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void canonical_scan_kernel(const void* __restrict__ rows, int64_t N, int D,
-                                                             const float* __restrict__ qv, float* __restrict__ dist) {
+                                                             const float* __restrict__ qv, float* __restrict__ dist,
+                                                             const float* __restrict__ inv) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p16 = lane & 15, sub = lane >> 4;
     const float* qp = qv + 4 * p16;
@@ -930,8 +956,11 @@ __global__ __launch_bounds__(256) void canonical_scan_kernel(const void* __restr
             for (int j = 0; j < 4; ++j) acc[j] = acc[j] + __shfl_xor(acc[j], o);
         }
         const double t0 = acc[0] + acc[2], t1 = acc[1] + acc[3];
-        const double dot = t0 + t1;
-        if (p16 == 0 && live) dist[row] = (float)(1.0 - dot);
+        double dot = t0 + t1;
+        if (p16 == 0 && live) {
+            if constexpr (sizeof(T) == 1) dot = dot * (double)inv[row];
+            dist[row] = (float)(1.0 - dot);
+        }
     }
 }
 
@@ -1056,6 +1085,16 @@ __global__ __launch_bounds__(256) void gather_rows_f32_kernel(const T* __restric
         const int64_t r = i / D;
         const int d = (int)(i - r * D);
         dst[i] = (float)src[map[r] * D + d];
+    }
+}
+// fp8 rows as the vectors they represent: value x inv[row] (one f32 multiply)
+__global__ __launch_bounds__(256) void gather_rows_f8_f32_kernel(const F8* __restrict__ src, const float* __restrict__ inv,
+                                                                 const int64_t* __restrict__ map, float* __restrict__ dst, int64_t n, int D) {
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int d = (int)(i - r * D);
+        dst[i] = (float)src[map[r] * D + d] * inv[map[r]];
     }
 }
 __global__ void gather_i64_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ map,

@@ -31,7 +31,13 @@ class FlatIndex:
         h = C.c_void_p()
         _lib.check(self._lib.mmiss_index_create(self.dim, self.dtype, self.device, int(capacity), C.byref(h)))
         self._h = h
-        self._call_lock = threading.Lock()
+        # re-entrant: a PendingQuery collected by the cyclic GC on a thread that is inside one of these calls must not
+        # deadlock that thread on itself
+        self._call_lock = threading.RLock()
+        # generation of the handle's ONE open-query slot: bumped by every query_begin, result and abort. A PendingQuery only
+        # ends / aborts the C-side query while its own generation is still the current one, so a stale handle that outlives
+        # its query (kept alive by a traceback or a reference cycle) cannot abort a newer query of someone else.
+        self._query_gen = 0
 
     # ------------------------------------------------------------------ helpers
     def _vecs(self, v):
@@ -131,7 +137,10 @@ class FlatIndex:
             self._sync_stream(q)
             fn = self._lib.mmiss_index_query_begin if split else self._lib.mmiss_index_query
             _lib.check(fn(self._h, _lib.ptr(q), Q, int(k), _lib.ptr(lab), _lib.ptr(dist), _lib.ptr(cnt)))
-        return PendingQuery(self, q, (lab, dist, cnt)) if split else (lab, dist, cnt)
+            if split:
+                self._query_gen += 1
+                return PendingQuery(self, q, (lab, dist, cnt), self._query_gen)
+        return (lab, dist, cnt)
 
     def guard_stats(self) -> dict:
         """Exactness accounting (mmiss_index_guard_stats_ex): queries served, queries whose first pass could not be proven
@@ -152,13 +161,16 @@ class FlatIndex:
     def abort_query(self) -> None:
         """Drop a query opened with query_begin() whose handle was lost (mmiss_index_query_abort); no-op otherwise."""
         with self._call_lock:
+            self._query_gen += 1   # whatever handle held the open query is stale from here on
             _lib.check(self._lib.mmiss_index_query_abort(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.mmiss_index_query_abort(self._h)   # (an abandoned PendingQuery must not outlive its buffers)
-            self._lib.mmiss_index_destroy(self._h)
-            self._h = None
+            with self._call_lock:
+                self._query_gen += 1
+                self._lib.mmiss_index_query_abort(self._h)   # (an abandoned PendingQuery must not outlive its buffers)
+                self._lib.mmiss_index_destroy(self._h)
+                self._h = None
 
     def __del__(self):
         try:
@@ -168,27 +180,40 @@ class FlatIndex:
 
 
 class PendingQuery:
-    """A query between FlatIndex.query_begin and its result(): holds the query rows and the output buffers alive."""
+    """A query between FlatIndex.query_begin and its result(): holds the query rows and the output buffers alive. It owns the
+    index's open-query slot only while its generation is the index's current one (FlatIndex._query_gen)."""
 
-    def __init__(self, index: "FlatIndex", q, outs):
-        self._index, self._q, self._outs, self._done = index, q, outs, False
+    def __init__(self, index: "FlatIndex", q, outs, gen: int):
+        self._index, self._q, self._outs, self._gen, self._done = index, q, outs, gen, False
+
+    def _current(self) -> bool:
+        idx = self._index
+        return getattr(idx, "_h", None) is not None and idx._query_gen == self._gen
 
     def result(self):
         if not self._done:
-            with self._index._call_lock:
+            idx = self._index
+            with idx._call_lock:
+                if not self._current():
+                    self._done = True
+                    self._q = None
+                    raise RuntimeError("this query was aborted (FlatIndex.abort_query / close, or a later query_begin)")
                 self._done = True   # (whatever _end returns, the C side has closed the query)
-                _lib.check(self._index._lib.mmiss_index_query_end(self._index._h))
+                idx._query_gen += 1
+                _lib.check(idx._lib.mmiss_index_query_end(idx._h))
             self._q = None
         return self._outs
 
     def abort(self) -> None:
         """Give the query up (mmiss_index_query_abort): waits for the queued first pass, delivers nothing, frees the index
-        for other calls. Also what happens when the handle is dropped or leaves a `with` block without result()."""
+        for other calls. Also what happens when the handle is dropped or leaves a `with` block without result(). A handle
+        whose query is no longer the index's open one (already aborted through the index, or superseded) does nothing."""
         if not self._done:
             self._done = True
             idx = self._index
-            if getattr(idx, "_h", None):
-                with idx._call_lock:
+            with idx._call_lock:
+                if self._current():
+                    idx._query_gen += 1
                     idx._lib.mmiss_index_query_abort(idx._h)
             self._q = None
 

@@ -132,8 +132,23 @@ static int cmp_hit(const void* a, const void* b) {
 
 /* queries: raw float32 [Q,D]; stored: mo_normalize_rows output [N,D]; labels int64 [N].
  * out_labels [Q,k], out_dist [Q,k], out_count [Q]; unused slots -1 / +inf. */
+static void mo_query_impl(const float* queries, int Q, const void* stored, int dtype, int64_t N, int D, const int64_t* labels,
+                          int k, int64_t* out_labels, float* out_dist, int32_t* out_count, const float* inv);
+
 void mo_query(const float* queries, int Q, const void* stored, int dtype, int64_t N, int D, const int64_t* labels,
               int k, int64_t* out_labels, float* out_dist, int32_t* out_count) {
+    mo_query_impl(queries, Q, stored, dtype, N, D, labels, k, out_labels, out_dist, out_count, NULL);
+}
+
+/* MMISS_F8 rows: stored = the float32 VALUES of the codes (dtype 0), inv[r] = float(1 / canonical norm of row r's values);
+ * distance = (float)(1.0 - canon_dot(q^, values[r]) * (double)inv[r])  (retrieval_oracle.py F8Rows) */
+void mo_query_f8(const float* queries, int Q, const float* values, const float* inv, int64_t N, int D, const int64_t* labels,
+                 int k, int64_t* out_labels, float* out_dist, int32_t* out_count) {
+    mo_query_impl(queries, Q, values, 0, N, D, labels, k, out_labels, out_dist, out_count, inv);
+}
+
+static void mo_query_impl(const float* queries, int Q, const void* stored, int dtype, int64_t N, int D, const int64_t* labels,
+                          int k, int64_t* out_labels, float* out_dist, int32_t* out_count, const float* inv) {
     float* qn = (float*)malloc((size_t)D * sizeof(float));
     hit_t* heap = (hit_t*)malloc((size_t)k * sizeof(hit_t));
     const size_t elt = dtype == 1 ? 2 : 4;
@@ -142,7 +157,9 @@ void mo_query(const float* queries, int Q, const void* stored, int dtype, int64_
         int n = 0;
         for (int64_t r = 0; r < N; ++r) {
             hit_t h;
-            h.dist = (float)(1.0 - canon_dot(qn, (const char*)stored + (size_t)r * D * elt, dtype, D));
+            double dot = canon_dot(qn, (const char*)stored + (size_t)r * D * elt, dtype, D);
+            if (inv) dot = dot * (double)inv[r];
+            h.dist = (float)(1.0 - dot);
             h.label = labels[r];
             if (h.dist != h.dist) continue; /* NaN rows are never returned */
             if (n < k) {

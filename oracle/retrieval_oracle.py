@@ -24,6 +24,7 @@ Canonical arithmetic (shared bit for bit with the HIP rerank kernel, csrc/retrie
   norm(x)              = sqrt(canon_sum(x*x))               (float64)
   normalize(x)         = float32(float64(x) / norm(x)), then the storage rounding (float16: RNE)
   distance(q, c)       = float32(1.0 - canon_sum(float64(q^) * float64(c_stored)))
+                         fp8 rows (F8Rows): float32(1.0 - canon_sum(float64(q^) * float64(values)) * float64(inv))
   order                = (distance ascending, label ascending)
 Products of float32 values are exact in float64, so the only roundings are the additions, in the fixed
 order above.
@@ -55,6 +56,41 @@ def canon_norm(x: np.ndarray) -> np.ndarray:
     return np.sqrt(canon_sum(x64 * x64))
 
 
+class F8Rows(np.ndarray):
+    """Stored form of MMISS_F8 rows (include/mmiss.h): float32 [N, D] VALUES the e4m3 codes stand for (decode(code) / 128) plus
+    `.inv`, float32 [N]: inv[r] = float32(1 / canon_norm(values[r])). The row the index represents is values[r] * inv[r] (unit
+    norm up to inv's own rounding), a distance is float32(1 - canon_sum(q^ * values[r]) * float64(inv[r])). Indexing with a
+    slice / index array / mask on the first axis keeps `.inv` in step; anything else yields a plain ndarray."""
+
+    def __new__(cls, values: np.ndarray, inv: np.ndarray):
+        obj = np.ascontiguousarray(values, dtype=np.float32).view(cls)
+        obj.inv = np.ascontiguousarray(inv, dtype=np.float32)
+        assert obj.ndim == 2 and obj.inv.shape == (obj.shape[0],)
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.inv = None   # (views made by numpy itself carry no inverse norms; __getitem__ below re-attaches them)
+
+    def __getitem__(self, key):
+        out = np.asarray(self)[key]
+        rows = key[0] if isinstance(key, tuple) else key
+        whole_rows = not isinstance(key, tuple) or all(isinstance(k, slice) and k == slice(None) for k in key[1:])
+        if self.inv is not None and whole_rows and out.ndim == 2 and not isinstance(rows, (int, np.integer)):
+            return F8Rows(out, self.inv[rows])
+        return out
+
+    def represented(self) -> np.ndarray:
+        """float32 [N, D]: values * inv, one float32 multiply per element — what mmiss_index_get returns for fp8 rows."""
+        return (np.asarray(self) * self.inv[:, None]).astype(np.float32)
+
+
+def concat_rows(parts):
+    """np.concatenate for stored rows of any dtype (F8Rows keep their inverse norms)."""
+    if all(isinstance(p, F8Rows) for p in parts):
+        return F8Rows(np.concatenate([np.asarray(p) for p in parts]), np.concatenate([p.inv for p in parts]))
+    return np.concatenate(parts)
+
+
 def normalize_rows(x: np.ndarray, dtype: str = "f32") -> np.ndarray:
     """Stored form of added vectors: float32(x / norm) then storage rounding."""
     x = np.asarray(x, dtype=np.float32)
@@ -69,7 +105,11 @@ def normalize_rows(x: np.ndarray, dtype: str = "f32") -> np.ndarray:
         from oracle import fp8_oracle
 
         codes = fp8_oracle.e4m3_encode(y * np.float32(128.0))
-        return (fp8_oracle.e4m3_decode(codes).astype(np.float32) * np.float32(1.0 / 128.0)).astype(np.float32)
+        vals = (fp8_oracle.e4m3_decode(codes).astype(np.float32) * np.float32(1.0 / 128.0)).astype(np.float32)
+        # one float per row: the inverse of the canonical norm of the values (csrc/retrieval_kernels.h f8_row_inv_kernel)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = (1.0 / canon_norm(vals)).astype(np.float32)
+        return F8Rows(vals, inv)
     return y
 
 
@@ -78,10 +118,17 @@ def distances(q_raw: np.ndarray, stored: np.ndarray, block: int = 4096) -> np.nd
     normalize_rows output (float32 or float16)."""
     qn = normalize_rows(q_raw, "f32").astype(np.float64)
     out = np.empty((qn.shape[0], stored.shape[0]), dtype=np.float32)
-    for r0 in range(0, stored.shape[0], block):
-        c = stored[r0:r0 + block].astype(np.float32).astype(np.float64)
+    inv = getattr(stored, "inv", None)
+    if isinstance(stored, F8Rows) and inv is None:
+        raise ValueError("F8Rows lost their inverse norms (use row slices / concat_rows)")
+    vals = np.asarray(stored)
+    for r0 in range(0, vals.shape[0], block):
+        c = vals[r0:r0 + block].astype(np.float32).astype(np.float64)
         for qi in range(qn.shape[0]):
-            out[qi, r0:r0 + block] = (1.0 - canon_sum(c * qn[qi])).astype(np.float32)
+            dot = canon_sum(c * qn[qi])
+            if inv is not None:
+                dot = dot * inv[r0:r0 + block].astype(np.float64)   # fp8 rows: the represented row is values * inv
+            out[qi, r0:r0 + block] = (1.0 - dot).astype(np.float32)
     return out
 
 

@@ -20,8 +20,10 @@ def _lib():
         _LIB.mo_normalize_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         _LIB.mo_query.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB.mo_query_f8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB.mo_blend.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p]
-        for f in (_LIB.mo_normalize_rows, _LIB.mo_query, _LIB.mo_blend):
+        for f in (_LIB.mo_normalize_rows, _LIB.mo_query, _LIB.mo_query_f8, _LIB.mo_blend):
             f.restype = None
     return _LIB
 
@@ -40,12 +42,19 @@ def query(q_raw: np.ndarray, stored: np.ndarray, labels: np.ndarray, k: int):
     q = np.ascontiguousarray(q_raw, dtype=np.float32)
     if q.ndim == 1:
         q = q[None]
-    stored = np.ascontiguousarray(stored)
+    inv = getattr(stored, "inv", None)   # retrieval_oracle.F8Rows: fp8 rows carry one inverse norm each
+    stored = np.ascontiguousarray(np.asarray(stored))
     labels = np.ascontiguousarray(labels, dtype=np.int64)
     Q, D = q.shape
     ol = np.empty((Q, k), dtype=np.int64)
     od = np.empty((Q, k), dtype=np.float32)
     oc = np.empty((Q,), dtype=np.int32)
+    if inv is not None:
+        inv = np.ascontiguousarray(inv, dtype=np.float32)
+        assert stored.dtype == np.float32 and inv.shape == (stored.shape[0],)
+        _lib().mo_query_f8(q.ctypes.data, Q, stored.ctypes.data, inv.ctypes.data, stored.shape[0], D, labels.ctypes.data, k,
+                           ol.ctypes.data, od.ctypes.data, oc.ctypes.data)
+        return ol, od, oc
     _lib().mo_query(q.ctypes.data, Q, stored.ctypes.data, 1 if stored.dtype == np.float16 else 0, stored.shape[0], D,
                     labels.ctypes.data, k, ol.ctypes.data, od.ctypes.data, oc.ctypes.data)
     return ol, od, oc

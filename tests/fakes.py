@@ -18,12 +18,16 @@ class OracleIndex:
         labels = np.asarray(labels, np.int64).reshape(-1)
         if self.labs.size and labels[0] <= self.labs[-1] or np.any(np.diff(labels) <= 0):
             raise RuntimeError("labels must be strictly increasing")
-        self.rows = np.concatenate([self.rows, ro.normalize_rows(np.asarray(vecs, np.float32), self.dtype)])
+        new = ro.normalize_rows(np.asarray(vecs, np.float32), self.dtype)
+        self.rows = ro.concat_rows([self.rows, new]) if self.rows.shape[0] else new
         self.labs = np.concatenate([self.labs, labels])
 
     def update(self, labels, vecs):
         for l, v in zip(np.asarray(labels).reshape(-1), np.asarray(vecs, np.float32).reshape(-1, self.dim)):
-            self.rows[int(np.nonzero(self.labs == l)[0][0])] = ro.normalize_rows(v, self.dtype)[0]
+            i, new = int(np.nonzero(self.labs == l)[0][0]), ro.normalize_rows(v, self.dtype)
+            np.asarray(self.rows)[i] = np.asarray(new)[0]
+            if getattr(new, "inv", None) is not None:
+                self.rows.inv[i] = new.inv[0]
 
     def remove(self, labels):
         keep = ~np.isin(self.labs, np.asarray(labels, np.int64))
@@ -42,7 +46,8 @@ class OracleIndex:
 
     def get(self, labels):
         idx = [int(np.nonzero(self.labs == l)[0][0]) for l in np.asarray(labels).reshape(-1)]
-        return self.rows[idx].astype(np.float32)
+        rows = self.rows[idx]
+        return rows.represented() if hasattr(rows, "represented") else rows.astype(np.float32)
 
     def query(self, q, k):
         q = np.asarray(q, np.float32)

@@ -172,3 +172,28 @@ def test_a_torn_vector_journal_tail_is_cut_off(colmod, tmp_path, torn_bytes):
     assert third.count() == 9
     assert third.query(query_embeddings=v[7:8], n_results=1)["ids"] == [["img_7"]]
     assert third.query(query_embeddings=v[2:3], n_results=1)["ids"] == [["img_2"]]
+
+
+@pytest.mark.parametrize("torn_bytes", [3, 512, 700])
+def test_torn_vectors_of_a_generations_first_mutation_are_cut_off(colmod, tmp_path, torn_bytes):
+    """the crash may hit the FIRST journaled mutation of a generation — torn bytes in the vector file and no
+    .jsonl file at all. Replay used to return early on the missing commit log, the next add recorded an offset behind the
+    orphan bytes (unaligned, or owned by nobody), and the restart after that one declared its record torn and cut the whole log
+    back to nothing: every mutation acknowledged after the crash was lost."""
+    client = colmod.PersistentClient(path=str(tmp_path))
+    col = client.create_collection("image-match", metadata={"hnsw:space": "cosine"})
+    v = _vecs(8, seed=31)
+    jl, jv = col._journal_paths(col._index_gen)
+    assert not os.path.exists(jl)
+    with open(jv, "wb") as f:
+        f.write(b"\x7f" * torn_bytes)                    # the first add's vectors, torn; its commit line never written
+    second = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert second.count() == 0 and os.path.getsize(jv) == 0
+    for i in range(4):
+        second.add(ids=[f"img_{i}"], embeddings=[v[i].tolist()], metadatas=[{"n": i}])
+    assert os.path.getsize(jv) == 4 * 128 * 4
+    third = colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match")
+    assert third.count() == 4                            # (was 0)
+    assert third.query(query_embeddings=v[2:3], n_results=1)["ids"] == [["img_2"]]
+    third.add(ids=["img_4"], embeddings=[v[4].tolist()])
+    assert colmod.PersistentClient(path=str(tmp_path)).get_collection("image-match").count() == 5

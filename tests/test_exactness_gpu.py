@@ -251,12 +251,11 @@ def test_a_clustered_index_where_every_query_is_widened(mods, dtype, Q):
     assert after["widened"] - before["widened"] >= Q * (0.5 if dtype == "f8" else 0.9), (before, after)
     assert after["rounds"] - before["rounds"] == 1 and after["exhaustive"] == before["exhaustive"], (before, after)
     assert after["swept_rows"] - before["swept_rows"] >= Q * k
-    if dtype != "f8":
-        # (an fp8 row is stored un-renormalised after its e4m3 rounding — |stored| within 3 % of 1, include/mmiss.h — which is
-        # more than the 1 % between a row and its neighbours here: the index is exact for its STORED rows, the oracle check
-        # below, but a row need not come first for its own unquantised vector)
-        assert (dist[:, 0] < 1e-4).all()
-        np.testing.assert_array_equal(lab[:, 0], labels[sel])
+    # configs[1]'s own check: every embedding finds ITSELF first. fp8 rows carry their inverse norm (round 5), so what comes
+    # back is a cosine distance: the row's own unquantised vector lies within the e4m3 rounding of its direction (1 - cos
+    # < 4e-3, typically 7e-4), its neighbours 1e-2 away.
+    assert (dist[:, 0] < (4e-3 if dtype == "f8" else 1e-4)).all(), dist[:, 0].max()
+    np.testing.assert_array_equal(lab[:, 0], labels[sel])
     sub = np.arange(0, Q, max(1, Q // 16))
     ol, od, oc = ro.query(q[sub], stored, labels, k)
     np.testing.assert_array_equal(lab[sub], ol)

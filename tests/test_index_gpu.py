@@ -39,7 +39,8 @@ def test_query_matches_oracle(mods, dtype, N, D):
     idx.add(c, labels)
     assert idx.count() == N
     stored = ro.normalize_rows(c, dtype)
-    np.testing.assert_array_equal(idx.get(labels[: min(N, 64)]), stored[: min(N, 64)].astype(np.float32))
+    head = stored[: min(N, 64)]   # (fp8 rows: get() returns the vectors the rows represent, values x inverse norm)
+    np.testing.assert_array_equal(idx.get(labels[: min(N, 64)]), head.represented() if dtype == "f8" else head.astype(np.float32))
     for Q, k in [(1, 1), (1, 10), (3, 10), (17, 10), (40, 5), (2, 24), (70, 10)]:
         q = _corpus(Q, D, seed=1000 + Q + k)
         _check(idx, ro, stored, labels, q, k)
@@ -561,10 +562,82 @@ def test_an_abandoned_query_handle_does_not_wedge_the_index(mods, tmp_path):
     del h
 
 
+def test_a_stale_query_handle_cannot_abort_a_newer_query(mods):
+    """PendingQuery.abort() / __del__ used to abort whatever query was open on the index. A handle that
+    outlives its query (aborted through the index; kept alive by a traceback or a cycle) must not abort the query someone
+    else has begun since — its abort() is a no-op and its result() raises; collecting it while the index lock is held by the
+    same thread must not deadlock (re-entrant lock)."""
+    FlatIndex, _, _, ro = mods
+    N, D, k = 3000, 256, 10
+    c = _corpus(N, D, seed=91)
+    labels = np.arange(N, dtype=np.int64)
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    q1, q2 = _corpus(4, D, seed=92), _corpus(6, D, seed=93)
+    stale = idx.query_begin(q1, k)
+    idx.abort_query()                       # the serving loop gives the open query up through the index
+    fresh = idx.query_begin(q2, k)          # ... and someone else begins the next one
+    with idx._call_lock:                    # collected by the GC inside a locked call of the same thread: no self-deadlock,
+        stale.__del__()                     # and it must NOT close `fresh`
+    del stale
+    lab, dist, cnt = fresh.result()
+    ol, od, oc = ro.query(q2, ro.normalize_rows(c, "f16"), labels, k)
+    np.testing.assert_array_equal(lab, ol)
+    np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+    np.testing.assert_array_equal(cnt, oc)
+    stale = idx.query_begin(q1, k)
+    idx.abort_query()
+    with pytest.raises(RuntimeError, match="aborted"):
+        stale.result()                      # a result that was never computed is not handed out
+    _check(idx, ro, ro.normalize_rows(c, "f16"), labels, q1, k)
+
+
+@pytest.mark.parametrize("dtype,D,Q", [("f32", 768, 40), ("f32", 768, 70), ("f32", 1024, 40), ("f32", 1024, 70), ("f16", 2048, 40),
+                                       ("f8", 2048, 40), ("f32", 1920, 33)])
+def test_widen_scan_fits_the_lds_at_every_admitted_dim(mods, dtype, D, Q):
+    """the streaming threshold pass of the widen pass sized its query block as 64 queries whenever more than
+    32 were flagged, without the 160 KB bound plan_scan applies — f32 rows at the reference's D = 768 need 64 x 3088 B = 193 KB
+    and the launch failed. Every query forced through the widen pass (guard_force) at the dims where 64 (or 32) staged queries
+    do not fit; the score-GEMM form of the pass is switched off so that the scan takes them."""
+    from mmiss_amd import _lib
+
+    FlatIndex, _, _, ro = mods
+    N, k = 3001, 10
+    c = _corpus(N, D, seed=D + Q)
+    labels = np.arange(N, dtype=np.int64) * 2 + 1
+    idx = FlatIndex(D, dtype)
+    idx.add(c, labels)
+    q = _corpus(Q, D, seed=7 * D + Q)
+    _lib.set_option("guard_force", 1)
+    _lib.set_option("sweep_gemm_min_q", 1 << 20)
+    try:
+        before = idx.guard_stats()
+        _check(idx, ro, ro.normalize_rows(c, dtype), labels, q, k)
+        after = idx.guard_stats()
+    finally:
+        _lib.set_option("guard_force", 0)
+        _lib.set_option("sweep_gemm_min_q", 64)
+    assert after["widened"] - before["widened"] == Q and after["exhaustive"] == before["exhaustive"]
+
+
+def test_create_refuses_dims_whose_query_block_cannot_fit(mods):
+    """The scan stages 16 queries beside its lists in the CU's 160 KB: f32 rows up to dim 1920, f16 / fp8 rows up to 3968 —
+    refused at create time (it used to be a failed launch at the first query)."""
+    FlatIndex = mods[0]
+    for dtype, D in [("f32", 2048), ("f32", 4096), ("f16", 4096), ("f8", 4096)]:
+        with pytest.raises(RuntimeError, match="LDS"):
+            FlatIndex(D, dtype)
+    for dtype, D in [("f32", 1920), ("f16", 3968)]:
+        FlatIndex(D, dtype).close()
+
+
 def test_fp8_rows_rank_like_the_f32_rows_up_to_their_quantisation(mods):
-    """MMISS_F8 storage (e4m3 codes of 128 x, include/mmiss.h): the index is exact with respect to its STORED rows (the tests
-    above, against the oracle's restatement of the rounding); against the unquantised rows the stored rows lie within a few
-    1e-3 in cosine, a planted near-duplicate is still found first, and the top-10 overlaps the f32 index's in >= 8 of 10."""
+    """MMISS_F8 storage (e4m3 codes of 128 x + one inverse norm per row, include/mmiss.h): the index is exact with respect to the
+    rows it REPRESENTS (the tests above, against the oracle's restatement of the rounding), and what it returns is a cosine
+    distance (round 5: the codes alone have norms 0.97 .. 1.03): the represented rows have unit norm, a row queried with itself
+    comes back at distance ~1e-7, with its unquantised original within the e4m3 rounding (< 4e-3). Against the unquantised
+    rows: a planted near-duplicate is still found first, the top-10 overlaps the f32 index's in >= 8 of 10 on average, and
+    the distances agree to what the rows' directions moved by."""
     FlatIndex, _, _, ro = mods
     N, D = 20000, 512
     c = _corpus(N, D, seed=71)
@@ -574,6 +647,7 @@ def test_fp8_rows_rank_like_the_f32_rows_up_to_their_quantisation(mods):
     s8, s32 = ro.normalize_rows(c, "f8"), ro.normalize_rows(c, "f32")
     cosrow = (s8.astype(np.float64) * s32).sum(1) / np.linalg.norm(s8.astype(np.float64), axis=1)
     assert (1 - cosrow).max() < 4e-3 and abs(np.linalg.norm(s8.astype(np.float64), axis=1) - 1).max() < 0.03
+    assert abs(np.linalg.norm(s8.represented().astype(np.float64), axis=1) - 1).max() < 3e-7
     i8, i32 = FlatIndex(D, "f8"), FlatIndex(D, "f32")
     i8.add(c, labels)
     i32.add(c, labels)
@@ -582,4 +656,13 @@ def test_fp8_rows_rank_like_the_f32_rows_up_to_their_quantisation(mods):
     assert l8[3, 0] == 777 and l32[3, 0] == 777
     overlap = [len(set(l8[i]) & set(l32[i])) for i in range(16)]
     assert min(overlap) >= 7 and np.mean(overlap) >= 8.5, overlap
-    assert np.abs(d8 - d32).max() < 3e-2
+    assert np.abs(d8 - d32).max() < 2e-2
+    # cosine distances: a represented row against itself, and the unquantised originals against their rows
+    own = np.arange(100, 164)
+    ls, ds, _ = i8.query(i8.get(labels[own]), 1)
+    np.testing.assert_array_equal(ls[:, 0], labels[own])
+    assert np.abs(ds[:, 0]).max() < 5e-7, ds[:, 0]
+    lo, do, _ = i8.query(c[own], 1)
+    np.testing.assert_array_equal(lo[:, 0], labels[own])
+    assert (do[:, 0] >= -1e-7).all() and do[:, 0].max() < 4e-3, do[:, 0]
+    np.testing.assert_allclose(do[:, 0], 1 - cosrow[own], atol=2e-6)

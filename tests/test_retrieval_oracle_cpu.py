@@ -126,6 +126,15 @@ def test_fp8_storage_rounding_is_e4m3_of_128x():
     nrm = np.linalg.norm(s8.astype(np.float64), axis=1)
     cos = (s8.astype(np.float64) * s32).sum(1) / nrm
     assert abs(nrm - 1).max() < 0.02 and (1 - cos).max() < 2e-3
-    # the oracle's query works on the stored values unchanged: self-query of a stored row returns it first
-    l, d, _ = ro.query(s8[7:8], s8, np.arange(500, dtype=np.int64), 3)
-    assert l[0, 0] == 7 and abs(d[0, 0] - (1 - float(nrm[7]))) < 1e-6   # distance to itself = 1 - |stored row| (q is normalised, the row is not)
+    # one inverse norm per row (round 5): the REPRESENTED row values * inv has unit norm, so a distance is a cosine distance —
+    # the self-query of a stored row returns it first at distance 0 (it was 1 - |values| = up to 0.03 with the codes alone)
+    np.testing.assert_allclose(s8.inv, (1.0 / nrm).astype(np.float32), rtol=2e-7)
+    assert abs(np.linalg.norm(s8.represented().astype(np.float64), axis=1) - 1).max() < 3e-7
+    l, d, _ = ro.query(np.asarray(s8[7:8]), s8, np.arange(500, dtype=np.int64), 3)
+    assert l[0, 0] == 7 and abs(d[0, 0]) < 2e-7
+    l, d, _ = ro.query(c[7:8], s8, np.arange(500, dtype=np.int64), 3)     # the unquantised original: 1 - cos of the rounding
+    assert l[0, 0] == 7 and abs(d[0, 0] - (1 - cos[7])) < 2e-7
+    # row slices, index arrays and concat_rows keep the inverse norms in step; a column slice is a plain array
+    assert np.array_equal(s8[10:20].inv, s8.inv[10:20]) and np.array_equal(s8[[3, 1]].inv, s8.inv[[3, 1]])
+    assert np.array_equal(ro.concat_rows([s8[:5], s8[9:12]]).inv, np.concatenate([s8.inv[:5], s8.inv[9:12]]))
+    assert type(s8[:, :8]) is np.ndarray and type(s8[4]) is np.ndarray
