@@ -6,6 +6,7 @@
 #include "gemm_bf16_p256.h"
 #include "gemm_bf16_p160.h"
 #include "gemm_fp8.h"
+#include "gemm_fp8_p256.h"
 #include "encoder_kernels.h"
 #include "preprocess_kernels.h"
 #include <map>
@@ -286,6 +287,18 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     if (const int f = mmiss_option("gemm_bm_mlp", 0)) bm_mlp = f;
     auto padded = [&](int bm) { return (int)round_up(M, bm % 1000); };
     const int bm8_qkv = gemm_pick_bm(M, 3 * d), bm8_d = gemm_pick_bm(M, d), bm8_mlp = gemm_pick_bm(M, tw.mlp);
+    // fp8 GEMMs on the persistent 256 x 256 kernel (gemm_fp8_p256.h, round 5) once there is a tile per CU; K % 512 == 0 (ViT-L/14:
+    // every GEMM; ViT-B/32: FC2 only). Option gemm_p256_fp8 = 0 turns it off, n > 1 = minimum tile count.
+    const int p8_min = mmiss_option("gemm_p256_fp8", 1);
+    auto p8 = [&](int epi, int N, int K) {
+        if (p8_min == 0 || !gemm256p8_ok(epi, (int)round_up(M, 256), N, K)) return false;
+        return (int64_t)(round_up(M, 256) / 256) * (N / 256) >= (p8_min > 1 ? p8_min : 256);
+    };
+    auto gemm8_any = [&](int epi, int bm, Gemm8Args g8) -> int {   // g8.M unset: padded here to the kernel's tile height
+        if (p8(epi, g8.N, g8.K)) { g8.M = (int)round_up(M, 256); return launch_gemm256p8(st, epi, g8); }
+        g8.M = (int)round_up(M, bm % 1000);
+        return launch_gemm8(st, epi, bm, g8);
+    };
     // 256 x 256 phase-pipelined tile for the widest GEMMs. Round 1 used it from N = 4096 (the ViT-L/14 FC1: 336 -> 320 us);
     // with the banded tile order the 128-column kernel now does that GEMM in 292 us (312 us on the 256 x 256 tile, whose
     // 2064 tiles are 8.06 rounds of 256 CUs), so it is off by default. Option gemm_256 = minimum N, 0 = never.
@@ -403,8 +416,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             Gemm8Args g{};
             g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
             g.W = L.wqkv8.as<uint8_t>(); g.wscale = L.sqkv.as<float>(); g.bias = L.bqkv.as<float>();
-            g.out = tw.qkv.p; g.ldo = 3 * d; g.M = padded(bm8_qkv); g.N = 3 * d; g.K = d; g.m_valid = M;
-            MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_BF16, bm8_qkv, g));
+            g.out = tw.qkv.p; g.ldo = 3 * d; g.N = 3 * d; g.K = d; g.m_valid = M;
+            MM_TRY(gemm8_any(MMISS_EPI8_BIAS_BF16, bm8_qkv, g));
         } else if (sfold) {
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = d / 16; ep.ln_eps = eps; ep.stats16 = 1;
@@ -458,8 +471,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             Gemm8Args g{};
             g.A = tw.ctx8.as<uint8_t>(); g.As = tw.ctxs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
             g.W = L.wo8.as<uint8_t>(); g.wscale = L.so.as<float>(); g.bias = L.bo.as<float>();
-            g.out = tw.xb.p; g.ldo = d; g.M = padded(bm8_d); g.N = d; g.K = d; g.m_valid = M;
-            MM_TRY(launch_gemm8(st, MMISS_EPI8_BIAS_RESID_BF16, bm8_d, g));
+            g.out = tw.xb.p; g.ldo = d; g.N = d; g.K = d; g.m_valid = M;
+            MM_TRY(gemm8_any(MMISS_EPI8_BIAS_RESID_BF16, bm8_d, g));
         } else if (resid16) {  // the bf16 rows ARE the residual stream: read-modify-write in place, no f32 stream
             ep.out = tw.xb.p; ep.xb_out = nullptr;
             if (p160(d, d)) MM_TRY(launch_gemm160p(st, tw.ctx.p, L.wo.p, ep, padded(160), d, d));
@@ -488,13 +501,13 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
             g.W = L.w1_8.as<uint8_t>(); g.wscale = L.s1.as<float>(); g.bias = L.b1.as<float>();
             g.out = tw.u8.p; g.out_scale = tw.us.as<uint8_t>(); g.ld_os = mx_scale_row_bytes(tw.mlp);
-            g.ldo = tw.mlp; g.M = padded(bm8_mlp); g.N = tw.mlp; g.K = d; g.m_valid = M;
-            MM_TRY(launch_gemm8(st, MMISS_EPI8_QGELU_MXFP8, bm8_mlp, g));
+            g.ldo = tw.mlp; g.N = tw.mlp; g.K = d; g.m_valid = M;
+            MM_TRY(gemm8_any(MMISS_EPI8_QGELU_MXFP8, bm8_mlp, g));
             g = Gemm8Args{};
             g.A = tw.u8.as<uint8_t>(); g.As = tw.us.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(tw.mlp);
             g.W = L.w2_8.as<uint8_t>(); g.wscale = L.s2.as<float>(); g.bias = L.b2.as<float>();
-            g.out = resid16 ? tw.xb.p : tw.x.p; g.ldo = d; g.M = padded(bm8_d); g.N = d; g.K = tw.mlp; g.m_valid = M;
-            MM_TRY(launch_gemm8(st, resid16 ? MMISS_EPI8_BIAS_RESID_BF16 : MMISS_EPI8_BIAS_RESID_F32, bm8_d, g));
+            g.out = resid16 ? tw.xb.p : tw.x.p; g.ldo = d; g.N = d; g.K = tw.mlp; g.m_valid = M;
+            MM_TRY(gemm8_any(resid16 ? MMISS_EPI8_BIAS_RESID_BF16 : MMISS_EPI8_BIAS_RESID_F32, bm8_d, g));
             MM_TRY(tap(l + 1));
             continue;
         } else if (sfold) {
@@ -1443,6 +1456,10 @@ extern "C" int mmiss_dbg_gemm8(int device, void* hip_stream, int epi, int bm, co
     g.W = reinterpret_cast<const uint8_t*>(W8); g.wscale = wscale; g.bias = bias; g.out = out;
     g.out_scale = reinterpret_cast<uint8_t*>(out_scale); g.ld_os = mx_scale_row_bytes(N);
     g.M = M; g.N = N; g.K = K; g.ldo = N; g.m_valid = M;
+    if (bm >= 256) {   // the persistent 256 x 256 kernel (gemm_fp8_p256.h); bm = 256 + v: only the first v rows are valid
+        if (bm > 256) g.m_valid = bm - 256 < M ? bm - 256 : M;
+        return launch_gemm256p8(reinterpret_cast<hipStream_t>(hip_stream), epi, g);
+    }
     return launch_gemm8(reinterpret_cast<hipStream_t>(hip_stream), epi, bm, g);
 }
 

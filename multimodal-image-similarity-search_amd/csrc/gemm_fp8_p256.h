@@ -1,0 +1,527 @@
+// gemm_fp8_p256.h — PERSISTENT 256x256x128 block-scaled fp8 (MXFP8) GEMM: the contract of gemm_fp8.h
+// (C[M,N] = A8[M,K] * W8[N,K]^T with the BIAS_BF16 / QGELU_MXFP8 / BIAS_RESID_BF16 epilogues, the same bytes out) on the
+// loop of gemm_bf16_p256.h. BASELINE configs[4] (ViT-L/14 fp8 encode, the reference's model: backend/app/utils.py:16-17):
+// QKV, FC1, FC2 and the out-projection of the vision tower at batch 128 (33 024 padded rows).
+//
+// Why: gemm8_kernel is the BM x 128 tile with two barriers and a drained pipeline per K-tile — 1.5-1.6 PF,
+// 30-32 % of the 5 PF fp8 roof, the structure the guide caps at ~36 %. A 128-element fp8 K-tile is the same 128 bytes per
+// row as a 64-element bf16 one: the LDS image, the buffer-form LDS-DMA staging, the XOR swizzle, the fragment reads (two
+// ds_read_b128 per 16-row sub-tile: k = 16 g .. + 15 and 64 + 16 g .. + 15 of lane group g — exactly the two chunks the bf16
+// fragments take) and the phase structure of gemm256p_kernel carry over unchanged; a phase's 16 bf16 MFMAs of 4 passes
+// become 8 v_mfma_scale_f32_16x16x128_f8f6f4 of 8 passes: the same matrix-pipe time per K-tile for twice the flops.
+//   * one workgroup per CU walks its tiles as ONE K-tile stream (prefetch t+1 / t+2 runs across tile boundaries, the
+//     epilogue out of the accumulators while the next tile's first K-tiles fly), wave halves one barrier apart;
+//   * what is new is the third operand, the activations' E8M0 block scales (one byte per row and 32 k, laid out per row as
+//     16 bytes per 512 k: dword c = k-block c of four consecutive K-tiles, gemm_fp8.h). They arrive by LDS-DMA as well (an
+//     ordinary load beside LDS-DMA drains the pipeline): ONE 4-byte piece per wave at the head of every K-tile PAIR — pair p
+//     of a tile brings the scale dwords of slot rows of A m(p & 1) for the 512-k group AFTER the one pair p lies in (for the
+//     tile's last group: group 0 of the workgroup's next tile) into a two-parity ring of 2 x 4 KB, so the piece count per
+//     pair is constant and every counted wait is an immediate: the four waits behind a piece allow one more operation in
+//     flight, the fifth retires it, a barrier later (and a whole K-tile before the group starts) every wave may read it.
+//     A lane reads its scale as ONE byte (ds_read_u8 at ring + row * 16 + 4 g + K-tile-in-group): OPSEL stays 0.
+//   * epilogue inputs — bias[256] (waves 0-3) and the weights' per-channel scales (waves 4-7) of the next tile — one 4-byte
+//     piece per wave, as in the bf16 kernel; the bf16 residual rows of BIAS_RESID_BF16 by ordinary loads at the head of the
+//     epilogue (the fragment registers are dead there), transposed to the accumulator layout through the wave's 2 KB patch.
+// K % 512 == 0 (an even number of pairs per tile: the scale pieces of a group need two), M, N % 256 == 0.
+#pragma once
+#include <type_traits>
+#include "gemm_fp8.h"
+#include "gemm_bf16_256.h"
+
+#define Q256_BC (8 * G256_SLOT)        // 2 x 2 KB: bias [256] f32 + wscale [256] f32 of the current / next tile
+#define Q256_TILES (Q256_BC + 4096)    // this workgroup's tile list: 64 x packed (bm, bn, half)
+#define Q256_RING (Q256_TILES + 256)   // 2 x 4 KB: scale dwords [parity][A slot mq][slot row 128][k-block 4]
+#define Q256_PATCH (Q256_RING + 8192)  // 8 waves x 2 KB: the epilogue's transposes
+#define Q256_LDS (Q256_PATCH + 16384)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(EPI == MMISS_EPI8_BIAS_BF16 || EPI == MMISS_EPI8_QGELU_MXFP8 || EPI == MMISS_EPI8_BIAS_RESID_BF16, "epilogue");
+    constexpr int EX = 16 + 1;  // vector-memory operations of a wave between two tiles' K streams: 16 stores + the bias / wscale piece
+    // An (unused) value of the accumulator register class makes the compiler select the MFMAs in their AGPR form: the 128
+    // accumulators live in a[0:127], the 128 arch VGPRs are left to the 8-register operand tuples of the K = 128 MFMA, the
+    // addresses and the epilogue. With everything in one file of 256 registers the allocator could not keep sixteen 8-tuples
+    // beside 32 scattered 4-tuples (40-50 spilled registers) — and a spill is a vector-memory operation the counted waits do
+    // not know about.
+    { int agpr_form_; asm volatile("" : "=a"(agpr_form_)); }
+#define Q256_PIN "+a"
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int M = g.M, N = g.N, K = g.K;
+    const int nbm = M >> 8, nbn = N >> 8;
+    const int nt = K >> 7;          // K-tiles per tile, a multiple of 4
+    const int npair = nt >> 1;      // even
+    const int ngrp = nt >> 2;       // 512-k scale groups per tile
+    __builtin_assume(npair >= 2);   // (K >= 512: no zero-trip copies of the K loop, whose accumulator joins cost registers)
+
+    // ---- tile list (gemm256p_kernel: rounds of G tiles of a banded global order; a last round of at most G/2 tiles in halves)
+    const int T = nbm * nbn, G = gridDim.x;
+    const int pb = xcd_remap(blockIdx.x, G);
+    const int full_rounds = T / G, rem = T - full_rounds * G;
+    const bool halves = full_rounds >= 1 && rem > 0 && 2 * rem <= G;
+    const int nfull = full_rounds + ((!halves && pb < rem) ? 1 : 0);
+    const int nhalf = (halves && pb < 2 * rem) ? 1 : 0;
+    const int mine = nfull + nhalf;
+    if (tid < mine && tid < 64) {
+        const bool hf = tid >= nfull;
+        const int L = hf ? full_rounds * G + (pb >> 1) : tid * G + pb;
+        int bm_, bn_;
+        tile_order(L, nbm, nbn, g.m_fast, bm_, bn_);
+        reinterpret_cast<unsigned*>(smem + Q256_TILES)[tid] = (unsigned)bm_ | ((unsigned)bn_ << 16) | (hf ? (1u << 30) : 0u) |
+                                                             ((hf && (pb & 1)) ? (1u << 31) : 0u);
+    }
+    __syncthreads();
+    auto tile_of = [&](int i, int& bm, int& bn, int& half) {  // half: 0 whole tile, 1 / 2 = its m0 / m1 rows only
+        const unsigned pk = (unsigned)__builtin_amdgcn_readfirstlane(((const __attribute__((address_space(3))) int*)(smem + Q256_TILES))[i]);
+        bm = pk & 0xffff;
+        bn = (pk >> 16) & 0x3fff;
+        half = (pk >> 30) ? 1 + (int)(pk >> 31) : 0;
+    };
+
+    // ---- LDS-DMA sources, buffer form. Slot row r of an A slot is the activation row (r>>6)*128 + mq*64 + (r&63) of the tile,
+    // of a W slot the weight row (r>>5)*64 + nq*32 + (r&31); a wave stages slot rows 16*wave .. +15 as two 8-row pieces of
+    // 128-byte rows; XOR swizzle of the 16-byte chunk on the source side.
+    // Everything the K loop derives from the lane id is recomputed (a few dozen vector instructions) behind every epilogue
+    // from the hardware's lane count, not kept: held across the epilogue these ~10 registers were spilled and reloaded —
+    // scratch loads behind an s_waitcnt vmcnt(0), i.e. a drain of the staging pipeline per tile.
+    auto lane_now = [&]() -> int {   // (the mask comes out of an asm statement: the count is not hoisted out of the tile loop and kept)
+        unsigned ones = ~0u;
+        asm volatile("" : "+s"(ones));
+        return (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+    };
+    int a_vo, w_vo, s_vo;
+    uint32_t ab[2], wb[2], sc_lane;
+    auto lane_consts = [&]() {
+        const int l = lane_now();
+        const int r_in = l >> 3, p = l & 7;
+        const int src_chunk = (p ^ r_in) * 16;
+        a_vo = ((wave >> 2) * 128 + (wave & 3) * 16 + r_in) * K + src_chunk;
+        w_vo = ((wave >> 1) * 64 + (wave & 1) * 16 + r_in) * K + src_chunk;
+        // scale piece: lane = (slot row 16 wave + lane / 4, k-block lane & 3) of one A slot; the slot's rows in the scalar offset
+        s_vo = ((wave >> 2) * 128 + (wave & 3) * 16 + (l >> 2)) * g.ld_as + (l & 3) * 4;
+        const int fr = l & 15, fg = l >> 4;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            ab[s] = (wm * 64 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
+            wb[s] = (8 * G256_SLOT / 2) + (wn * 32 + fr) * 128 + (((4 * s + fg) ^ (fr & 7)) << 4);
+        }
+        // scale bytes: ring + parity * 4096 + mq * 2048 + (slot row wm*64 + mf*16 + fr) * 16 + fg * 4 + K-tile in group
+        sc_lane = Q256_RING + (wm * 64 + fr) * 16 + fg * 4;
+    };
+    lane_consts();
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g.A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdW = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g.W), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdS = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g.As), 0, 0x7fffffff, 0x00020000);
+    const int row8 = 8 * K;  // bytes between a slot's two 8-row pieces
+    const int stage_dst = wave * 2048;
+#define Q256_SLOT(which, b) (((which) * 2 + (b)) * G256_SLOT)
+#define Q256_BLDS(srd, vo, so, dst) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 16, vo, so, 0, 0)
+#define Q256_BLDS4(srd, vo, so, dst) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (__attribute__((address_space(3))) void*)(dst), 4, vo, so, 0, 0)
+// LIVE = false: the slot is not read (the A m1 slot of a half tile): its pieces shrink to 4 bytes per lane, the COUNT stays
+#define Q256_STAGE(which, b, oA, oW, LIVE)                                                                   \
+    {                                                                                                       \
+        char* dst_ = smem + Q256_SLOT(which, b) + stage_dst;                                                \
+        if constexpr ((which) < 2) {                                                                        \
+            const int so_ = (oA);                                                                           \
+            if (LIVE) {                                                                                     \
+                Q256_BLDS(srdA, a_vo, so_, dst_);                                                           \
+                Q256_BLDS(srdA, a_vo, so_ + row8, dst_ + 1024);                                             \
+            } else {                                                                                        \
+                Q256_BLDS4(srdA, a_vo, so_, dst_);                                                          \
+                Q256_BLDS4(srdA, a_vo, so_ + row8, dst_ + 1024);                                            \
+            }                                                                                               \
+        } else {                                                                                            \
+            const int so_ = (oW) + ((which) & 1) * 4 * row8;                                                \
+            Q256_BLDS(srdW, w_vo, so_, dst_);                                                               \
+            Q256_BLDS(srdW, w_vo, so_ + row8, dst_ + 1024);                                                 \
+        }                                                                                                   \
+    }
+    // bias / weight scales of tile (., bn): one 4-byte piece per wave
+    const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wave >= 4 ? g.wscale : g.bias), 0, 0x7fffffff, 0x00020000);
+    auto stage_x = [&](int bn, int par) {
+        const int l4 = lane_now() * 4;   // (recomputed: no 64-bit lane address kept)
+        Q256_BLDS4(srdX, l4, (bn * 256 + (wave & 3) * 64) * 4, smem + Q256_BC + par * 2048 + wave * 256);
+    };
+
+    // ---- fragment reads: one base per operand and 64-k half + immediates (slot, 16-row sub-tile)
+    typedef const __attribute__((address_space(3))) uint8_t* lds_u8;
+    v8i32 am[4];
+    v8i32 wq[2][2];
+    int sc[4];
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define Q256_READ_A(b, mq)                                                                                   \
+    _Pragma("unroll") for (int mf = 0; mf < 4; ++mf) {                                                      \
+        const u32x4 lo_ = *reinterpret_cast<const u32x4*>(smem + ab[0] + Q256_SLOT(mq, b) + mf * 2048);     \
+        const u32x4 hi_ = *reinterpret_cast<const u32x4*>(smem + ab[1] + Q256_SLOT(mq, b) + mf * 2048);     \
+        am[mf][0] = lo_[0]; am[mf][1] = lo_[1]; am[mf][2] = lo_[2]; am[mf][3] = lo_[3];                     \
+        am[mf][4] = hi_[0]; am[mf][5] = hi_[1]; am[mf][6] = hi_[2]; am[mf][7] = hi_[3];                     \
+        sc[mf] = (int)((lds_u8)smem)[sc_lane + sc_off + (mq) * 2048 + mf * 256];               \
+    }
+#define Q256_READ_W(b, nq)                                                                                   \
+    _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                                      \
+        const u32x4 lo_ = *reinterpret_cast<const u32x4*>(smem + wb[0] + Q256_SLOT(nq, b) + nf * 2048);     \
+        const u32x4 hi_ = *reinterpret_cast<const u32x4*>(smem + wb[1] + Q256_SLOT(nq, b) + nf * 2048);     \
+        wq[nq][nf][0] = lo_[0]; wq[nq][nf][1] = lo_[1]; wq[nq][nf][2] = lo_[2]; wq[nq][nf][3] = lo_[3];     \
+        wq[nq][nf][4] = hi_[0]; wq[nq][nf][5] = hi_[1]; wq[nq][nf][6] = hi_[2]; wq[nq][nf][7] = hi_[3];     \
+    }
+// 8 block-scaled MFMAs: weights = A operand (unit block scales), activations = B operand (scale byte 0 of sc[mf])
+#define Q256_MMA(mq, nq)                                                                                     \
+    {                                                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                      \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                    \
+            _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                                \
+                acc[(nq) * 2 + nf][(mq) * 4 + mf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(       \
+                    wq[nq][nf], am[mf], acc[(nq) * 2 + nf][(mq) * 4 + mf], 0, 0, 0, 0x7F7F7F7F, 0, sc[mf]); \
+        /* pinned: without a use at this point the optimiser sinks the MFMAs (pure functions of registers) behind the */ \
+        /* pair's sixteen barriers — every fragment of two K-tiles alive at once, 200+ spilled registers */       \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                    \
+            _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                                \
+                asm volatile("" : Q256_PIN(acc[(nq) * 2 + nf][(mq) * 4 + mf]));                                \
+        __builtin_amdgcn_s_setprio(0);                                                                      \
+    }
+// counted wait: 10 younger slot pieces stay in flight; POST: + the previous tile's epilogue operations; XS: + the pair's scale piece
+#define Q256_WAIT(POST, XS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 + ((POST) ? EX : 0) + ((XS) ? 1 : 0)) : "memory")
+#define Q256_BARRIER()                       \
+    {                                        \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    }
+#define Q256_LATE_READS_DONE() \
+    if (wm == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// One K-tile out of buffer B (gemm256p_kernel's P256_KTILE): four phases [reads + one slot's staging + wait] B [8 MFMAs] B.
+// P0 / P1 / P3: POST form of the three waits; X0 / X1 / X3: the pair's scale piece is younger than the slot the wait retires.
+#define Q256_KTILE(B, P0, P1, P3, X0, X1, X3, HALF)                                                          \
+    {                                                                                                       \
+        Q256_READ_A(B, 0);                                                                                  \
+        Q256_READ_W(B, 0);                                                                                  \
+        Q256_STAGE(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0); /* A m1 of K-tile t+1 */                          \
+        Q256_LATE_READS_DONE();                                                                             \
+        Q256_WAIT(P0, X0);                /* retires W n1 of this K-tile */                                 \
+        Q256_BARRIER();                                                                                     \
+        Q256_MMA(0, 0);                                                                                     \
+        Q256_BARRIER();                                                                                     \
+        Q256_READ_W(B, 1);                                                                                  \
+        Q256_STAGE(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                    \
+        Q256_LATE_READS_DONE();                                                                             \
+        Q256_WAIT(P1, X1);                /* retires A m1 of this K-tile */                                 \
+        Q256_BARRIER();                                                                                     \
+        Q256_MMA(0, 1);                                                                                     \
+        Q256_BARRIER();                                                                                     \
+        if constexpr (!(HALF)) { Q256_READ_A(B, 1); }                                                       \
+        Q256_STAGE(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
+        Q256_LATE_READS_DONE();                                                                             \
+        Q256_BARRIER();                                                                                     \
+        if constexpr (!(HALF)) { Q256_MMA(1, 1); }                                                          \
+        Q256_BARRIER();                                                                                     \
+        Q256_STAGE(3, B, oA2, oW2, true);       /* W n1 of K-tile t+2 */                                    \
+        Q256_WAIT(P3, X3);                /* retires A m0 / W n0 of the next K-tile */                      \
+        Q256_BARRIER();                                                                                     \
+        if constexpr (!(HALF)) { Q256_MMA(1, 0); }                                                          \
+        Q256_BARRIER();                                                                                     \
+        Q256_ADVANCE();                                                                                     \
+    }
+// position t+1 becomes the old t+2; t+2 moves on one K-tile (into the next tile, or wraps in the last one); the scale byte
+// offset moves on one K-tile: + 1 inside a group, other parity at a group's end
+#define Q256_ADVANCE()                                                                                       \
+    oA1 = oA2; oW1 = oW2; mA1 = mA2;                                                                        \
+    if (++k2 == nt) {                                                                                       \
+        k2 = 0;                                                                                             \
+        if (o2 + 1 < mine) ++o2;                                                                            \
+        int bm_, bn_, hf_;                                                                                  \
+        tile_of(o2, bm_, bn_, hf_);                                                                         \
+        oA2 = bm_ * 256 * K + (hf_ == 2 ? 8 * row8 : 0);                                                    \
+        oW2 = bn_ * 256 * K;                                                                                \
+        mA2 = hf_ ? 0 : 8 * row8;                                                                           \
+    } else {                                                                                                \
+        oA2 += 128; oW2 += 128;                                                                             \
+    }                                                                                                       \
+    sc_off = ((++kt_cur) & 3) == 0 ? ((sc_off & 4096) ^ 4096) : sc_off + 1;
+// the scale piece at the head of a pair: A slot `pc_mq` of scale group `pc_g` of tile position `pc_o` into the ring parity of
+// that group; then the cursor moves on (the tile's last group is followed by group 0 of the workgroup's next tile, whose
+// rows come from the tile list; past the last tile it re-reads the last one)
+#define Q256_SCALE_PIECE()                                                                                   \
+    {                                                                                                       \
+        Q256_BLDS4(srdS, s_vo, pc_so, smem + Q256_RING + pc_par + pc_mq * 2048 + wave * 256);               \
+        if (pc_mq == 0) { pc_mq = 1; pc_so += 64 * g.ld_as; }                                               \
+        else {                                                                                              \
+            pc_mq = 0; pc_par ^= 4096;                                                                      \
+            if (++pc_g == ngrp) {                                                                           \
+                pc_g = 0;                                                                                   \
+                if (pc_o + 1 < mine) ++pc_o;                                                                \
+                int bm_, bn_, hf_;                                                                          \
+                tile_of(pc_o, bm_, bn_, hf_);                                                               \
+                pc_so = (bm_ * 256 + (hf_ == 2 ? 64 : 0)) * g.ld_as;                                        \
+            } else {                                                                                        \
+                pc_so += 16 - 64 * g.ld_as;                                                                 \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    // ---- stream state
+    int cbm, cbn, chalf;
+    tile_of(0, cbm, cbn, chalf);
+    int oA1 = cbm * 256 * K + (chalf == 2 ? 8 * row8 : 0), oW1 = cbn * 256 * K;  // K-tile 0 of tile 0, then position t+1
+    int oA2 = oA1 + 128, oW2 = oW1 + 128;
+    int mA1 = chalf ? 0 : 8 * row8, mA2 = mA1;   // where a position's A m1 slot comes from (a half tile has none: m0 again)
+    int o2 = 0, k2 = 1;
+    int kt_cur = 0;                              // K-tile of the tile being computed (only its low two bits matter)
+    int sc_off = 0;                              // ring parity * 4096 + K-tile in its scale group
+    const int dump_row = M - 1;                  // rows >= m_valid are stored to the last pad row (the store COUNT must not depend on data)
+    // scale-piece cursor: group 0 of tile 0 goes out in the prologue (both slots), the loop starts with group 1 (or the next tile's group 0)
+    int pc_o = 0, pc_g = 0, pc_mq = 0, pc_par = 0;
+    int pc_so = (cbm * 256 + (chalf == 2 ? 64 : 0)) * g.ld_as;
+
+    // prologue: the first group's scale dwords, the first tile's bias / weight scales, K-tile 0 completely, K-tile 1 except its
+    // A m1 slot (staged by phase 0 of K-tile 0)
+    Q256_SCALE_PIECE();
+    Q256_SCALE_PIECE();
+    stage_x(cbn, 0);
+    {
+        char* d0 = smem + stage_dst;
+        Q256_BLDS(srdA, a_vo, oA1, d0 + Q256_SLOT(0, 0)); Q256_BLDS(srdA, a_vo, oA1 + row8, d0 + Q256_SLOT(0, 0) + 1024);
+        Q256_BLDS(srdW, w_vo, oW1, d0 + Q256_SLOT(2, 0)); Q256_BLDS(srdW, w_vo, oW1 + row8, d0 + Q256_SLOT(2, 0) + 1024);
+        Q256_BLDS(srdW, w_vo, oW1 + 4 * row8, d0 + Q256_SLOT(3, 0)); Q256_BLDS(srdW, w_vo, oW1 + 5 * row8, d0 + Q256_SLOT(3, 0) + 1024);
+        if (mA1 != 0) { Q256_BLDS(srdA, a_vo, oA1 + mA1, d0 + Q256_SLOT(1, 0)); Q256_BLDS(srdA, a_vo, oA1 + mA1 + row8, d0 + Q256_SLOT(1, 0) + 1024); }
+        else { Q256_BLDS4(srdA, a_vo, oA1, d0 + Q256_SLOT(1, 0)); Q256_BLDS4(srdA, a_vo, oA1 + row8, d0 + Q256_SLOT(1, 0) + 1024); }
+        Q256_BLDS(srdA, a_vo, oA2, d0 + Q256_SLOT(0, 1)); Q256_BLDS(srdA, a_vo, oA2 + row8, d0 + Q256_SLOT(0, 1) + 1024);
+        Q256_BLDS(srdW, w_vo, oW2, d0 + Q256_SLOT(2, 1)); Q256_BLDS(srdW, w_vo, oW2 + row8, d0 + Q256_SLOT(2, 1) + 1024);
+        Q256_BLDS(srdW, w_vo, oW2 + 4 * row8, d0 + Q256_SLOT(3, 1)); Q256_BLDS(srdW, w_vo, oW2 + 5 * row8, d0 + Q256_SLOT(3, 1) + 1024);
+    }
+    // position t+1 = K-tile 1 (its A m1 slot is still to come), t+2 = K-tile 2
+    oA1 = oA2; oW1 = oW2;
+    oA2 += 128; oW2 += 128;
+    k2 = 2;
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // all but the five youngest slot loads: A m0 / W n0 of K-tile 0, the pieces in front of them
+    Q256_BARRIER();
+    if (wm == 1) Q256_BARRIER();  // the lower half runs one barrier behind from here on
+
+    // ---- epilogue of the tile (cbm, cbn) out of the accumulators: JN = 8 (whole tile) or 4 (half tile: 64 rows per wave, hrow = 0 / 64)
+    // 16-row sub-tiles per wave. acc[i][j][r] = C[m = wm*128 + hrow + j*16 + fr][n = wn*64 + i*16 + 4*fg + r].
+    auto epilogue = [&](auto jn_c, int hrow, int par) {
+        constexpr int JN = decltype(jn_c)::value;
+        // the lane id from the hardware, here: nothing the epilogue derives from it is kept live (or spilled) through the K loop
+        const int lane_e = lane_now();
+        const int fr = lane_e & 15, fg = lane_e >> 4;
+        // bias and weight scale of this lane's four columns of column block i: read from LDS where they are used (32 registers
+        // held across the eight sub-tiles were the difference between fitting and spilling)
+        const char* bc = smem + Q256_BC + par * 2048 + (wn * 64 + 4 * fg) * 4;
+#define Q256_BIAS(i) (*reinterpret_cast<const f32x4*>(bc + (i) * 64))
+#define Q256_SW(i) (*reinterpret_cast<const f32x4*>(bc + 1024 + (i) * 64))
+        char* patch = smem + Q256_PATCH + wave * 2048;
+        const int rrow = lane_e >> 3, rchunk = lane_e & 7;
+        const int m_base = cbm * 256 + wm * 128 + hrow;
+        const int n_base = cbn * 256 + wn * 64;
+        const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, 0x7fffffff, 0x00020000);
+        if constexpr (EPI == MMISS_EPI8_BIAS_BF16 || EPI == MMISS_EPI8_BIAS_RESID_BF16) {
+            // 16 rows x 64 bf16 columns through the patch: 8-byte slot s of row r at slot s ^ 2 (r & 7); whole 128-byte rows per store
+            const int wr_off = fr * 128, wr_sw = 2 * (fr & 7);
+            // the residual rows, four 16-row sub-tiles (64 rows x 128 bytes per wave, 32 registers) fetched at a time
+            u32x4 old[EPI == MMISS_EPI8_BIAS_RESID_BF16 ? 4 : 1][2];
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                f32x4 res[4];
+                if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16) {
+                    if ((j & 3) == 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int rh = 0; rh < 2; ++rh) {
+                                const int m = m_base + (j + jj) * 16 + rh * 8 + rrow;
+                                const int vo = ((m < g.m_valid ? m : dump_row) * g.ldo + n_base + rchunk * 8) * 2;
+                                old[jj][rh] = __builtin_amdgcn_raw_buffer_load_b128(srdO, vo, 0, 0);
+                            }
+                    }
+                    // old rows -> accumulator layout: written as they were loaded (row rh*8 + rrow, chunk rchunk), read per (fr, i)
+#pragma unroll
+                    for (int rh = 0; rh < 2; ++rh) {
+                        const int row = rh * 8 + rrow;
+                        *reinterpret_cast<u32x4*>(patch + row * 128 + (((2 * rchunk) ^ (2 * (row & 7))) << 3)) = old[j & 3][rh];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x2 o2_ = *reinterpret_cast<const u32x2*>(patch + wr_off + (((i * 4 + fg) ^ wr_sw) << 3));
+                        res[i] = f32x4{__uint_as_float(o2_[0] << 16), __uint_as_float(o2_[0] & 0xFFFF0000u),
+                                       __uint_as_float(o2_[1] << 16), __uint_as_float(o2_[1] & 0xFFFF0000u)};
+                    }
+                    __builtin_amdgcn_wave_barrier();  // every lane has read before the patch is rewritten
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 y = acc[i][j] * Q256_SW(i) + Q256_BIAS(i);
+                    if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16) y = res[i] + y;
+                    u32x2 pk;
+                    pk[0] = pack_bf16x2(y[0], y[1]);
+                    pk[1] = pack_bf16x2(y[2], y[3]);
+                    *reinterpret_cast<u32x2*>(patch + wr_off + (((i * 4 + fg) ^ wr_sw) << 3)) = pk;
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int rh = 0; rh < 2; ++rh) {
+                    const int row = rh * 8 + rrow;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((2 * rchunk) ^ (2 * (row & 7))) << 3));
+                    const int m = m_base + j * 16 + row;
+                    const int vo = ((m < g.m_valid ? m : dump_row) * g.ldo + n_base + rchunk * 8) * 2;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, srdO, vo, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next j
+                __builtin_amdgcn_sched_barrier(0);   // (one sub-tile's accumulators in VGPRs at a time)
+            }
+        } else {
+            // QuickGELU -> MXFP8: ONE scale per row and the wave's 64 columns (= k-blocks n/32 and n/32 + 1 of the next GEMM, the
+            // same byte twice: gemm8_kernel's format), 16 rows x 64 bytes through the patch (80-byte rows), one store per j
+            const __amdgpu_buffer_rsrc_t srdQ = __builtin_amdgcn_make_buffer_rsrc(g.out_scale, 0, 0x7fffffff, 0x00020000);
+            const int sc_col = mx_scale_offset((n_base >> 5) + (fg & 1));   // lane groups 0 / 2 write the first byte, 1 / 3 the second
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                f32x4 y[4];
+                float amax = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    y[i] = acc[i][j] * Q256_SW(i) + Q256_BIAS(i);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        y[i][r] = quick_gelu(y[i][r]);
+                        amax = fmaxf(amax, fabsf(y[i][r]));
+                    }
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 16));
+                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                int e8;
+                float inv;
+                mx_scale_of(amax, e8, inv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<uint32_t*>(patch + fr * 80 + i * 16 + fg * 4) =
+                        pack_fp8x4(y[i][0] * inv, y[i][1] * inv, y[i][2] * inv, y[i][3] * inv);
+                {   // the row's scale byte: every lane stores (no data-dependent instruction count)
+                    const int m = m_base + j * 16 + fr;
+                    const int vo = (m < g.m_valid ? m : dump_row) * g.ld_os + sc_col;
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)e8, srdQ, vo, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+                    const int row = lane_e >> 2, c16 = lane_e & 3;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 80 + c16 * 16);
+                    const int m = m_base + j * 16 + row;
+                    const int vo = (m < g.m_valid ? m : dump_row) * g.ldo + n_base + c16 * 16;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, srdO, vo, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- whole tiles. Pair kp of a tile: scale piece, K-tile 2 kp out of buffer 0, K-tile 2 kp + 1 out of buffer 1.
+    for (int ti = 0; ti < nfull; ++ti) {
+        for (int kp = 0; kp < npair; ++kp) {
+            Q256_SCALE_PIECE();
+            if (kp == 0 && ti > 0) {
+                Q256_KTILE(0, true, true, true, true, true, true, false);
+                Q256_KTILE(1, true, false, false, true, false, false, false);
+            } else {
+                Q256_KTILE(0, false, false, false, true, true, true, false);
+                Q256_KTILE(1, false, false, false, true, false, false, false);
+            }
+        }
+        // The tile is complete. The upper half waits one barrier for the lower half's last MFMAs, both run the epilogue side
+        // by side, then the lower half falls one barrier behind again.
+        if (wm == 0) Q256_BARRIER();
+        epilogue(std::integral_constant<int, 8>{}, 0, ti & 1);
+        lane_consts();
+        if (ti + 1 < mine) {
+            tile_of(ti + 1, cbm, cbn, chalf);
+            stage_x(cbn, (ti + 1) & 1);
+            if (wm == 1) Q256_BARRIER();
+        }
+    }
+    // ---- the half tile of the last round, if this workgroup has one (always behind at least one whole tile: POST waits)
+    if (nhalf) {
+        for (int kp = 0; kp < npair; ++kp) {
+            Q256_SCALE_PIECE();
+            if (kp == 0) {
+                Q256_KTILE(0, true, true, true, true, true, true, true);
+                Q256_KTILE(1, true, false, false, true, false, false, true);
+            } else {
+                Q256_KTILE(0, false, false, false, true, true, true, true);
+                Q256_KTILE(1, false, false, false, true, false, false, true);
+            }
+        }
+        if (wm == 0) Q256_BARRIER();
+        epilogue(std::integral_constant<int, 4>{}, chalf == 2 ? 64 : 0, nfull & 1);
+    }
+    // the unconditional staging of the last K-tiles is still in flight: LDS must not be handed on with DMA writes pending
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#undef Q256_SLOT
+#undef Q256_PIN
+#undef Q256_BIAS
+#undef Q256_SW
+#undef Q256_BLDS
+#undef Q256_BLDS4
+#undef Q256_STAGE
+#undef Q256_READ_A
+#undef Q256_READ_W
+#undef Q256_MMA
+#undef Q256_WAIT
+#undef Q256_BARRIER
+#undef Q256_LATE_READS_DONE
+#undef Q256_KTILE
+#undef Q256_ADVANCE
+#undef Q256_SCALE_PIECE
+
+// can this GEMM run on the persistent fp8 kernel?
+static inline bool gemm256p8_ok(int epi, int M, int N, int K) {
+    if (M <= 0 || (M % 256) || N <= 0 || (N % 256) || K < 512 || (K % 512)) return false;
+    if ((int64_t)(M / 256) * (N / 256) > 48 * 256 || M / 256 > 0xffff) return false;  // (tile table: 64 entries per workgroup)
+    if ((int64_t)M * N * 2 >= (1LL << 31) || (int64_t)M * K >= (1LL << 31) || (int64_t)N * K >= (1LL << 31)) return false;  // (32-bit buffer offsets)
+    return epi == MMISS_EPI8_BIAS_BF16 || epi == MMISS_EPI8_QGELU_MXFP8 || epi == MMISS_EPI8_BIAS_RESID_BF16;
+}
+
+template <int EPI>
+static int launch_gemm256p8_inst(hipStream_t st, const Gemm8Args& g) {
+    const int T = (g.M / 256) * (g.N / 256);
+    const int grid = T >= 256 ? 256 : T;
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p8_kernel<EPI>), Q256_LDS));
+    hipLaunchKernelGGL((gemm256p8_kernel<EPI>), dim3(grid), dim3(512), Q256_LDS, st, g);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+// g.M = rows padded to 256 (A8, As, out and out_scale must hold g.M rows); rows >= g.m_valid are computed and land in row M - 1.
+static int launch_gemm256p8(hipStream_t st, int epi, Gemm8Args g) {
+    if (!gemm256p8_ok(epi, g.M, g.N, g.K) || !g.A || !g.As || !g.W || !g.wscale || !g.bias || !g.out || g.ld_as < mx_scale_row_bytes(g.K) ||
+        (int64_t)g.M * g.ld_as >= (1LL << 31))
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256p8: epi=%d M=%d N=%d K=%d ld_as=%d", epi, g.M, g.N, g.K, g.ld_as);
+    if (epi == MMISS_EPI8_QGELU_MXFP8 && (!g.out_scale || g.ld_os < mx_scale_row_bytes(g.N)))
+        MM_FAIL(MMISS_ERR_ARG, "gemm256p8: the MXFP8 epilogue needs out_scale with >= %d bytes per row", mx_scale_row_bytes(g.N));
+    if (g.m_fast == 0) g.m_fast = mmiss_option("gemm_p256_band", 8);  // row blocks per band of the global tile order
+    static const char* names[] = {"gemm_fp8_bias_p256", "gemm_fp8_qgelu_mx_p256", "", "gemm_fp8_bias_resid16_p256"};
+    const int mv = g.m_valid < g.M ? g.m_valid : g.M;
+    const double out_b = epi == MMISS_EPI8_BIAS_BF16 ? 2.0 : (epi == MMISS_EPI8_QGELU_MXFP8 ? 1.0 : 4.0);
+    MM_PROF(names[epi], st, 2.0 * mv * (double)g.N * g.K, (double)mv * g.K + (double)g.N * g.K + out_b * mv * g.N);
+    if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_BF16>(st, g);
+    if (epi == MMISS_EPI8_QGELU_MXFP8) return launch_gemm256p8_inst<MMISS_EPI8_QGELU_MXFP8>(st, g);
+    return launch_gemm256p8_inst<MMISS_EPI8_BIAS_RESID_BF16>(st, g);
+}

@@ -68,6 +68,10 @@ VIT_B32 = ClipShape()
 # ViT-L/14 towers with the reference HEAD's 248-token text table (backend/app/utils.py:16-17,41-42)
 LONGCLIP_L14 = ClipShape(v_hidden=1024, v_layers=24, v_heads=16, v_mlp=4096, v_patch=14, v_image=224,
                          t_hidden=768, t_layers=12, t_heads=12, t_mlp=3072, t_ctx=248, proj_dim=768)
+# ... and the same geometry two layers deep (patch 14 / 257 tokens / width 1024 / 16 heads; 248-token text tower of width
+# 768): what tests/golden/clip_l14_2layer.npz pins against transformers (tools/make_goldens.py)
+LONGCLIP_L14_2L = ClipShape(v_hidden=1024, v_layers=2, v_heads=16, v_mlp=4096, v_patch=14, v_image=224,
+                            t_hidden=768, t_layers=2, t_heads=12, t_mlp=3072, t_ctx=248, proj_dim=768)
 # small shape with the same structure (head_dim 64, dims multiples of 128) for fast parity tests
 TINY = ClipShape(v_hidden=128, v_layers=2, v_heads=2, v_mlp=256, v_patch=32, v_image=64,
                  t_hidden=128, t_layers=2, t_heads=2, t_mlp=256, t_vocab=1000, t_ctx=16, proj_dim=128,

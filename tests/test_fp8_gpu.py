@@ -144,11 +144,16 @@ def test_attention_with_mxfp8_output(env, B, T, H):
 
 
 @pytest.mark.parametrize("epi,bm,M,N,K", [(0, 128, 256, 256, 512), (0, 160, 320, 384, 768), (2, 192, 384, 128, 4096),
-                                          (1, 128, 128, 512, 1024), (1, 160, 480, 256, 768), (2, 128, 128, 256, 128)])
+                                          (1, 128, 128, 512, 1024), (1, 160, 480, 256, 768), (2, 128, 128, 256, 128),
+                                          (3, 128, 256, 256, 512),
+                                          # bm = 256: the persistent 256 x 256 kernel of round 5 (gemm_fp8_p256.h), K % 512 == 0
+                                          (0, 256, 512, 768, 512), (1, 256, 768, 512, 1024), (3, 256, 256, 1024, 2048),
+                                          (0, 256, 256, 256, 4096)])
 def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
     """A8 / W8 random e4m3 bytes, activation block scales spread over 2^-6 .. 2^5: the MFMA result must equal the float64
     product of the DEQUANTISED operands up to fp32 accumulation — this pins the operand layout, the lane <-> k-block <->
-    scale association and the OPSEL walk through the permuted scale words."""
+    scale association and the OPSEL walk through the permuted scale words (the persistent kernel: the scale ring, its two
+    parities and the K-tile-in-group byte)."""
     torch, _lib, lib, fo = env
     rng = np.random.default_rng(100 * epi + bm + K)
     tab = fo.e4m3_table()
@@ -170,6 +175,10 @@ def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
         out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
     elif epi == 1:
         out = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    elif epi == 3:
+        x0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(torch.bfloat16)
+        out = x0.clone().cuda()
+        x0 = x0.float().numpy()
     else:
         x0 = rng.standard_normal((M, N)).astype(np.float32)
         out = dev(x0)
@@ -188,6 +197,9 @@ def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
     elif epi == 2:
         got = out.cpu().numpy()
         assert (np.abs(got - (ref + x0)) <= tol_acc + 1e-5 * (np.abs(ref) + np.abs(x0))).all()
+    elif epi == 3:   # the bf16 residual stream updated in place: bf16(f32(old) + acc * ws + bias)
+        got = out.float().cpu().numpy()
+        assert (np.abs(got - (ref + x0)) <= tol_acc + np.abs(ref + x0) * 2.0 ** -8 + 1e-5 * np.abs(ref)).all()
     else:
         y = ref * (1.0 / (1.0 + np.exp(-1.702 * ref)))     # QuickGELU, HF:activations.py:117-123
         got_e = fo.unpermute_scales(osc.cpu().numpy(), N)
@@ -198,6 +210,46 @@ def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
         assert (np.abs(got_e[:, ::2].astype(int) - e_ref.astype(int)) <= 1).all() and (got_e[:, ::2] == e_ref).mean() > 0.99
         gmax = g64.repeat(64, axis=1)
         assert (np.abs(back - y) <= gmax * 2.0 ** -4 * 1.02 + tol_acc * 2 + 1e-6).all()
+
+
+@pytest.mark.parametrize("epi,M,mv,N,K", [(0, 33024, 32896, 3072, 1024), (1, 33024, 32896, 4096, 1024), (3, 33024, 32896, 1024, 1024),
+                                          (3, 33024, 32896, 1024, 4096), (0, 12800, 12800, 2304, 3072), (1, 2048, 2000, 512, 512),
+                                          (3, 16640, 16600, 768, 1536)])
+def test_persistent_fp8_gemm_equals_the_tile_kernel_bit_for_bit(env, epi, M, mv, N, K):
+    """gemm256p8_kernel (round 5: one workgroup per CU, ONE K-tile stream over its tiles, staggered wave halves, the block
+    scales through an LDS ring) against gemm8_kernel (BM x 128 tiles) on the same bytes: both sum a row's K-tiles in ascending
+    order on the same instruction and apply the same epilogue arithmetic, so every output byte must be equal — at BASELINE
+    configs[4]'s own shapes (ViT-L/14 at batch 128: 32 896 valid of 33 024 padded rows; QKV, FC1 -> MXFP8, out-projection and
+    FC2 on the bf16 residual stream: 2-8 whole tiles per workgroup plus the half tiles of the last round), ViT-B/32's FC2,
+    and two small grids (fewer tiles than CUs; a ragged last row block). Rows >= m_valid are not compared."""
+    torch, _lib, lib, fo = env
+    g = torch.Generator(device="cuda").manual_seed(1000 * epi + K + N)
+    tab = fo.e4m3_table()
+    ok = torch.from_numpy(np.nonzero(~np.isnan(tab) & (np.abs(tab) <= 16))[0].astype(np.uint8)).cuda()
+    A8 = ok[torch.randint(0, ok.numel(), (M, K), device="cuda", generator=g)]
+    W8 = ok[torch.randint(0, ok.numel(), (N, K), device="cuda", generator=g)]
+    e = torch.randint(121, 131, (M, K // 32), device="cuda", generator=g, dtype=torch.int32).to(torch.uint8)
+    As = torch.from_numpy(fo.permute_scales(e.cpu().numpy())).cuda()
+    ws = (torch.rand(N, device="cuda", generator=g) + 1.0) * 2.0 ** -7
+    bias = torch.randn(N, device="cuda", generator=g)
+    outs = []
+    for bm in (128, 256 + mv):
+        osc = torch.zeros((M, fo.scale_row_bytes(N)), dtype=torch.uint8, device="cuda")
+        if epi == 0:
+            out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        elif epi == 1:
+            out = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+        else:
+            out = torch.randn((M, N), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7)).to(torch.bfloat16)
+        for _ in range(2 if epi != 3 else 1):   # (twice: a second launch over warm caches must not differ; the in-place form once)
+            _lib.check(lib.mmiss_dbg_gemm8(0, None, epi, bm, A8.data_ptr(), As.data_ptr(), W8.data_ptr(), ws.data_ptr(),
+                                           bias.data_ptr(), out.data_ptr(), osc.data_ptr(), M, N, K))
+        torch.cuda.synchronize()
+        outs.append((out[:mv].view(torch.uint8) if epi != 1 else out[:mv], osc[:mv]))
+    assert torch.equal(outs[0][0], outs[1][0]), "output bytes differ in %d places" % int((outs[0][0] != outs[1][0]).sum())
+    if epi == 1:
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert int((outs[1][0] != 0).sum()) > 0.3 * mv * N
 
 
 def _fp8_vs_bf16_vs_oracle(shape, seed, B_img, B_txt, T):

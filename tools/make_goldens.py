@@ -80,9 +80,33 @@ def hf_vision_hidden_states(m, pixels):
     return [h.cpu().numpy() for h in vo.hidden_states]
 
 
+def l14_two_layers():
+    """The reference checkpoint's GEOMETRY (backend/app/utils.py:16-17,41-45: zer0int/LongCLIP-GmP-ViT-L-14 — ViT-L/14
+    vision tower, 248-row text position table, projection 768), two layers deep so that the file stays small and the
+    float32 forward takes seconds: patch 14 -> 257 tokens, width 1024, 16 heads, mlp 4096; text width 768, 12 heads,
+    248 positions. Embeddings + the vision hidden states behind pre-LN and behind layer 2 (first image only)."""
+    s = co.LONGCLIP_L14_2L
+    W = co.init_weights(s, seed=0)
+    m = hf_model(s, W)
+    rng = np.random.Generator(np.random.Philox(501))
+    px = rng.standard_normal((4, 3, s.v_image, s.v_image), dtype=np.float32)
+    ids = co.synthetic_text_ids(4, s.t_ctx, s.t_vocab, s.eos_token_id, seed=502, bos=49406)
+    e = reference_embeddings(m, s, px, ids)
+    hs = hf_vision_hidden_states(m, px[:1])   # (first image only: 1 MB per tap)
+    np.savez_compressed(os.path.join(OUT, "clip_l14_2layer.npz"), weight_seed=0, pixel_seed=501, ids=ids,
+                        image=e["image"], image_raw=e["image_raw"], text=e["text"],
+                        vis_hidden_0=hs[0].astype(np.float32), vis_hidden_last=hs[-1].astype(np.float32))
+    print("clip_l14_2layer.npz", os.path.getsize(os.path.join(OUT, "clip_l14_2layer.npz")) // 1024, "KiB; eos at",
+          co.eos_positions(ids, s.eos_token_id).tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "l14":   # only the file added in round 5 (the others are unchanged)
+        l14_two_layers()
+        return
+    l14_two_layers()
 
     # ---------------------------------------------------------------- tiny shape: embeddings + intermediates
     s = co.TINY
