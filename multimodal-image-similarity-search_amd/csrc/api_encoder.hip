@@ -7,6 +7,7 @@
 #include "gemm_bf16_p160.h"
 #include "gemm_fp8.h"
 #include "gemm_fp8_p256.h"
+#include "host_stager.h"
 #include "encoder_kernels.h"
 #include "preprocess_kernels.h"
 #include <map>
@@ -139,6 +140,7 @@ struct mmiss_encoder {
     // staging buffer while the current chunk is computed (ev_copied / ev_free order the two streams)
     DevBuf stage2[2];
     hipStream_t copy_stream = nullptr;
+    HostStager stager;   // pageable host inputs cross PCIe through its ring of pinned blocks (host_stager.h)
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     ResizeDesc* rz_host = nullptr;   // pinned; rz_copied marks the end of its last host->device copy
     size_t rz_host_cap = 0;
@@ -648,6 +650,23 @@ int finish_call(mmiss_encoder* e, hipStream_t st, bool must_sync) {
 
 // Resize + centre-crop images b0 .. b0+nb-1 of a raw RGB8 blob into dst_dev (uint8 [nb,S,S,3], device), on st.
 // `staged` != null: the chunk's byte range [its lo, its hi) of the host blob already sits at `staged` in HBM.
+// host bytes -> device on `stream`: through the handle's pinned ring from 4 MB on (option pinned_stage = 0: plain
+// hipMemcpyAsync from the caller's pageable memory, the round-4 form; stage_threads: host threads per block, default
+// min(8, hardware threads / 2)); small copies go directly — a single request must not pay for waking the copy threads
+static int enc_h2d(mmiss_encoder* enc, void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes >= (size_t)(4 << 20) && mmiss_option("pinned_stage", 1) != 0) {
+        if (!enc->stager.slot_bytes) {
+            const int hw = (int)std::thread::hardware_concurrency();
+            int nthr = mmiss_option("stage_threads", 0);
+            if (nthr <= 0) nthr = hw >= 2 ? (hw / 2 < 8 ? hw / 2 : 8) : 1;
+            MM_TRY(enc->stager.init((size_t)mmiss_option("stage_block_mb", 16) << 20, nthr));
+        }
+        return enc->stager.h2d(dst, src, bytes, stream);
+    }
+    MM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    return MMISS_OK;
+}
+
 int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb_bytes, const int64_t* offsets,
                  const int32_t* heights, const int32_t* widths, int b0, int nb, uint8_t* dst_dev, hipStream_t st,
                  const uint8_t* staged = nullptr) {
@@ -689,7 +708,7 @@ int resize_chunk(mmiss_encoder* e, const uint8_t* rgb, bool rgb_dev, int64_t rgb
         src = staged;
     } else if (!rgb_dev) {  // stage the byte range this chunk touches
         MM_TRY(e->raw_stage.ensure((size_t)(hi - lo)));
-        MM_HIP(hipMemcpyAsync(e->raw_stage.p, rgb + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+        MM_TRY(enc_h2d(e, e->raw_stage.p, rgb + lo, (size_t)(hi - lo), st));
         for (int i = 0; i < nb; ++i) e->rz_host[i].src_off -= lo;
         src = e->raw_stage.as<uint8_t>();
     }
@@ -794,6 +813,7 @@ extern "C" int mmiss_encoder_destroy(mmiss_encoder* enc) {
     if (enc->own_stream) (void)hipStreamDestroy(enc->own_stream);
     if (enc->rz_copied) (void)hipEventDestroy(enc->rz_copied);
     if (enc->done_ev) (void)hipEventDestroy(enc->done_ev);
+    enc->stager.shutdown();
     if (enc->copy_stream) (void)hipStreamDestroy(enc->copy_stream);
     for (int i = 0; i < 2; ++i) {
         if (enc->ev_copied[i]) (void)hipEventDestroy(enc->ev_copied[i]);
@@ -1001,7 +1021,7 @@ static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8
         MM_TRY(ensure_pipeline(enc));
         MM_TRY(enc->stage2[0].ensure(img_bytes * maxb));
         MM_TRY(enc->stage2[1].ensure(img_bytes * maxb));
-        MM_HIP(hipMemcpyAsync(enc->stage2[0].p, pixels, img_bytes * maxb, hipMemcpyHostToDevice, enc->copy_stream));
+        MM_TRY(enc_h2d(enc, enc->stage2[0].p, pixels, img_bytes * maxb, enc->copy_stream));
         MM_HIP(hipEventRecord(enc->ev_copied[0], enc->copy_stream));
     } else if (!in_dev) {
         MM_TRY(enc->pix_stage.ensure(img_bytes * maxb));
@@ -1013,7 +1033,7 @@ static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8
             MM_HIP(hipStreamWaitEvent(st, enc->ev_copied[k & 1], 0));
             src = enc->stage2[k & 1].as<char>();
         } else if (!in_dev) {
-            MM_HIP(hipMemcpyAsync(enc->pix_stage.p, src, img_bytes * nb, hipMemcpyHostToDevice, st));
+            MM_TRY(enc_h2d(enc, enc->pix_stage.p, src, img_bytes * nb, st));
             src = enc->pix_stage.as<char>();
         }
         float* dst = out_dev ? out + (size_t)b0 * P : enc->vis.out_stage.as<float>();
@@ -1023,8 +1043,8 @@ static int encode_image_impl(mmiss_encoder* enc, const void* pixels, bool src_u8
             if (b0 + maxb < B) {
                 const int nxt = (k + 1) & 1, b1 = b0 + maxb, n1 = (B - b1 < maxb) ? B - b1 : maxb;
                 if (k >= 1) MM_HIP(hipStreamWaitEvent(enc->copy_stream, enc->ev_free[nxt], 0));
-                MM_HIP(hipMemcpyAsync(enc->stage2[nxt].p, reinterpret_cast<const char*>(pixels) + (size_t)b1 * img_bytes,
-                                      img_bytes * n1, hipMemcpyHostToDevice, enc->copy_stream));
+                MM_TRY(enc_h2d(enc, enc->stage2[nxt].p, reinterpret_cast<const char*>(pixels) + (size_t)b1 * img_bytes, img_bytes * n1,
+                               enc->copy_stream));
                 MM_HIP(hipEventRecord(enc->ev_copied[nxt], enc->copy_stream));
             }
         }
@@ -1084,7 +1104,7 @@ static int encode_rgb_impl(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_b
         MM_TRY(enc->stage2[1].ensure((size_t)need + 4));
         int64_t lo, hi;
         rgb_chunk_range(offsets, heights, widths, 0, maxb, rgb_bytes, lo, hi);
-        MM_HIP(hipMemcpyAsync(enc->stage2[0].p, rgb + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, enc->copy_stream));
+        MM_TRY(enc_h2d(enc, enc->stage2[0].p, rgb + lo, (size_t)(hi - lo), enc->copy_stream));
         MM_HIP(hipEventRecord(enc->ev_copied[0], enc->copy_stream));
     }
     for (int b0 = 0, k = 0; b0 < B; b0 += maxb, ++k) {
@@ -1112,7 +1132,7 @@ static int encode_rgb_impl(mmiss_encoder* enc, const uint8_t* rgb, int64_t rgb_b
             int64_t lo, hi;
             rgb_chunk_range(offsets, heights, widths, b1, (B - b1 < maxb) ? B - b1 : maxb, rgb_bytes, lo, hi);
             if (k >= 1) MM_HIP(hipStreamWaitEvent(enc->copy_stream, enc->ev_free[nxt], 0));
-            MM_HIP(hipMemcpyAsync(enc->stage2[nxt].p, rgb + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, enc->copy_stream));
+            MM_TRY(enc_h2d(enc, enc->stage2[nxt].p, rgb + lo, (size_t)(hi - lo), enc->copy_stream));
             MM_HIP(hipEventRecord(enc->ev_copied[nxt], enc->copy_stream));
         }
         if (out_emb && !out_dev) {

@@ -46,6 +46,9 @@ struct Gemm8Args {
     int M, N, K, ldo, m_valid;
     int ld_as, ld_os;       // bytes per row of As / out_scale
     int m_fast;
+    // gemm256p8_kernel only: the last 256-row block holds `ragged` <= 128 valid rows (0: none). They are computed by a
+    // register-streamed pass of all workgroups in front of the tile stream; the tiles then cover M - 256 rows.
+    int ragged;
 };
 
 // bytes per row of a permuted scale array for K columns

@@ -22,6 +22,15 @@
 //   * epilogue inputs — bias[256] (waves 0-3) and the weights' per-channel scales (waves 4-7) of the next tile — one 4-byte
 //     piece per wave, as in the bf16 kernel; the bf16 residual rows of BIAS_RESID_BF16 by ordinary loads at the head of the
 //     epilogue (the fragment registers are dead there), transposed to the accumulator layout through the wave's 2 KB patch.
+//   * a RAGGED last row block (ViT-L/14 at batch 128: 32 896 = 128 x 256 + 128 rows) is not a tile: 128 row blocks x N / 256
+//     column tiles is a whole number of rounds of 256 CUs for every GEMM of the tower, 129 row blocks leave 4-16 tiles
+//     for a last round that costs 0.8 of a tile time on 8-32 CUs with the rest of the chip idle (QKV 6.8 tile times for
+//     6.05 of work, the N = 1024 GEMMs 2.8 for 2.02). The block's <= 128 valid rows are computed in front of the tile
+//     stream by ALL workgroups instead: units of 16 rows x 64 (or 32) columns, one or two per workgroup, a unit's K-tiles
+//     dealt over the eight waves (operands straight from global memory into registers, every load in flight at once — a
+//     GEMV-shaped job), the eight partial sums added in wave order through LDS, the epilogue by wave 0. ~4 us instead of
+//     13-44. (The partial sums make these rows differ from gemm8_kernel's in the last bits of the f32 sums; the tile rows
+//     stay bit-identical.)
 // K % 512 == 0 (an even number of pairs per tile: the scale pieces of a group need two), M, N % 256 == 0.
 #pragma once
 #include <type_traits>
@@ -33,6 +42,18 @@
 #define Q256_RING (Q256_TILES + 256)   // 2 x 4 KB: scale dwords [parity][A slot mq][slot row 128][k-block 4]
 #define Q256_PATCH (Q256_RING + 8192)  // 8 waves x 2 KB: the epilogue's transposes
 #define Q256_LDS (Q256_PATCH + 16384)
+
+// max over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four lane groups that hold one row's columns) by two swaps in the vector unit
+// (v_permlane32_swap, v_permlane16_swap): __shfl_xor's ds_bpermute takes its address from the lane id, a register the
+// compiler computes once and then keeps — or spills — across the whole K stream
+__device__ __forceinline__ float q256_max_over_lane_groups(float v) {
+    uint32_t u = __float_as_uint(v);
+    auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+    u = __float_as_uint(v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
@@ -52,11 +73,131 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int M = g.M, N = g.N, K = g.K;
-    const int nbm = M >> 8, nbn = N >> 8;
+    const int nbm = (M >> 8) - (g.ragged > 0 ? 1 : 0), nbn = N >> 8;   // (a ragged last row block is not a tile)
     const int nt = K >> 7;          // K-tiles per tile, a multiple of 4
     const int npair = nt >> 1;      // even
     const int ngrp = nt >> 2;       // 512-k scale groups per tile
     __builtin_assume(npair >= 2);   // (K >= 512: no zero-trip copies of the K loop, whose accumulator joins cost registers)
+
+    // ---- the ragged last row block, in front of everything (no LDS-DMA is in flight yet: ordinary loads, ordinary waits)
+    if (g.ragged > 0) {
+        const int lane = tid & 63;
+        const int fr = lane & 15, fg = lane >> 4;
+        const int row0 = M - 256;                                   // first row of the block
+        const int rgroups = (g.ragged + 15) >> 4;                   // 16-row groups with a valid row
+        // columns per unit: the narrowest of 32 / 64 / 128 that leaves at most one unit per workgroup (the MXFP8 epilogue scales
+        // a row per 64 columns: at least 64); ViT-L/14: N = 1024 -> 32 (256 units), 3072 -> 128 (192), 4096 -> 128 (256)
+        int cw = EPI == MMISS_EPI8_QGELU_MXFP8 ? 64 : 32;
+        while (cw < 128 && rgroups * (N / cw) > (int)gridDim.x) cw <<= 1;
+        const int ncol = cw >> 4;                                   // 16-column MFMA tiles per unit (2, 4 or 8)
+        const int units = rgroups * (N / cw);
+        f32x4* red = reinterpret_cast<f32x4*>(smem);                // [wave][column tile][lane]: 8 x 8 x 64 x 16 B = 64 KB
+        // NC = 16-column tiles per unit, a COMPILE-TIME count: with a run-time bound every load of the unrolled loops sat
+        // behind its own branch and its own s_waitcnt vmcnt(0) — twenty dependent memory round trips per unit (guide, trap (c))
+        auto ragged_units = [&](auto nc_tag) {
+            constexpr int NC = decltype(nc_tag)::value;
+            constexpr int NE = NC < 4 ? NC : 4;                     // column tiles per epilogue wave
+            for (int u = blockIdx.x; u < units; u += gridDim.x) {
+                const int rg = u % rgroups, cg = u / rgroups;
+                const int m = row0 + rg * 16 + fr;                  // this lane's activation row (pad rows of the block are readable)
+                const int n0 = cg * cw;
+                f32x4 racc[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) racc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const uint8_t* ap = g.A + (size_t)m * K + fg * 16;
+                const uint8_t* sp = g.As + (size_t)m * g.ld_as + fg * 4;
+                const uint8_t* wp = g.W + (size_t)(n0 + fr) * K + fg * 16;
+                for (int kt = wave; kt < nt; kt += 8) {              // this wave's K-tiles of the unit
+                    const u32x4 alo = *reinterpret_cast<const u32x4*>(ap + kt * 128);
+                    const u32x4 ahi = *reinterpret_cast<const u32x4*>(ap + kt * 128 + 64);
+                    const int scw = *reinterpret_cast<const int*>(sp + (kt >> 2) * 16);     // four K-tiles' scales of k-block fg
+                    u32x4 wlo[NC], whi[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        wlo[c] = *reinterpret_cast<const u32x4*>(wp + (size_t)c * 16 * K + kt * 128);
+                        whi[c] = *reinterpret_cast<const u32x4*>(wp + (size_t)c * 16 * K + kt * 128 + 64);
+                    }
+                    const v8i32 af = __builtin_bit_cast(v8i32, __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    const int scb = (int)((unsigned)scw >> (8 * (kt & 3))) & 0xff;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const v8i32 wf = __builtin_bit_cast(v8i32, __builtin_shufflevector(wlo[c], whi[c], 0, 1, 2, 3, 4, 5, 6, 7));
+                        racc[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, af, racc[c], 0, 0, 0, 0x7F7F7F7F, 0, scb);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) red[(wave * 8 + c) * 64 + lane] = racc[c];
+                // the epilogue's operands fly while the partial sums settle: wave e < NC / 4 (wave 0 alone for 32 columns) takes
+                // the unit's 16-column tiles 4 e .. 4 e + 3
+                const int c0 = wave * 4;
+                const bool epi_wave = c0 < NC;
+                const bool live = m < g.m_valid;
+                f32x4 wsv[NE], bv[NE];
+                u32x2 oldv[NE];
+                if (epi_wave) {
+#pragma unroll
+                    for (int c = 0; c < NE; ++c) {
+                        const int n = n0 + (c0 + c) * 16 + 4 * fg;
+                        wsv[c] = *reinterpret_cast<const f32x4*>(g.wscale + n);
+                        bv[c] = *reinterpret_cast<const f32x4*>(g.bias + n);
+                        if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16)
+                            oldv[c] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(g.out) + (size_t)(live ? m : M - 1) * g.ldo + n);
+                    }
+                }
+                __syncthreads();
+                if (epi_wave) {
+                    // y[c][r] = C[m = row fr of the group][n = n0 + (c0 + c) * 16 + 4 * fg + r]: the eight partial sums in wave order
+                    f32x4 y[NE];
+                    float amax = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NE; ++c) {
+                        f32x4 sum = red[(c0 + c) * 64 + lane];
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) sum = sum + red[(w * 8 + c0 + c) * 64 + lane];
+                        y[c] = sum * wsv[c] + bv[c];
+                        if constexpr (EPI == MMISS_EPI8_QGELU_MXFP8) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                y[c][r] = quick_gelu(y[c][r]);
+                                amax = fmaxf(amax, fabsf(y[c][r]));
+                            }
+                        }
+                    }
+                    const int nb = n0 + c0 * 16;   // first column of this wave's (up to) 64
+                    if constexpr (EPI == MMISS_EPI8_QGELU_MXFP8) {      // (cw >= 64: four whole column tiles)
+                        amax = q256_max_over_lane_groups(amax);
+                        int e8;
+                        float inv;
+                        mx_scale_of(amax, e8, inv);
+                        if (live) {
+#pragma unroll
+                            for (int c = 0; c < NE; ++c)
+                                *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g.out) + (size_t)m * g.ldo + nb + c * 16 + 4 * fg) =
+                                    pack_fp8x4(y[c][0] * inv, y[c][1] * inv, y[c][2] * inv, y[c][3] * inv);
+                            if (fg < 2) g.out_scale[(size_t)m * g.ld_os + mx_scale_offset((nb >> 5) + fg)] = (uint8_t)e8;
+                        }
+                    } else if (live) {
+                        uint16_t* orow = reinterpret_cast<uint16_t*>(g.out) + (size_t)m * g.ldo + nb + 4 * fg;
+#pragma unroll
+                        for (int c = 0; c < NE; ++c) {
+                            if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16)
+                                y[c] = f32x4{__uint_as_float(oldv[c][0] << 16), __uint_as_float(oldv[c][0] & 0xFFFF0000u),
+                                             __uint_as_float(oldv[c][1] << 16), __uint_as_float(oldv[c][1] & 0xFFFF0000u)} + y[c];
+                            u32x2 pk;
+                            pk[0] = pack_bf16x2(y[c][0], y[c][1]);
+                            pk[1] = pack_bf16x2(y[c][2], y[c][3]);
+                            *reinterpret_cast<u32x2*>(orow + c * 16) = pk;
+                        }
+                    }
+                }
+                __syncthreads();   // `red` is rewritten by the next unit, then handed to the tile stream
+            }
+        };
+        if (ncol == 8) ragged_units(std::integral_constant<int, 8>{});
+        else if (ncol == 4) ragged_units(std::integral_constant<int, 4>{});
+        else if constexpr (EPI != MMISS_EPI8_QGELU_MXFP8) ragged_units(std::integral_constant<int, 2>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     // ---- tile list (gemm256p_kernel: rounds of G tiles of a banded global order; a last round of at most G/2 tiles in halves)
     const int T = nbm * nbn, G = gridDim.x;
@@ -403,8 +544,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                     }
                     acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                amax = fmaxf(amax, __shfl_xor(amax, 16));
-                amax = fmaxf(amax, __shfl_xor(amax, 32));
+                amax = q256_max_over_lane_groups(amax);
                 int e8;
                 float inv;
                 mx_scale_of(amax, e8, inv);
@@ -501,7 +641,7 @@ static inline bool gemm256p8_ok(int epi, int M, int N, int K) {
 
 template <int EPI>
 static int launch_gemm256p8_inst(hipStream_t st, const Gemm8Args& g) {
-    const int T = (g.M / 256) * (g.N / 256);
+    const int T = (g.M / 256 - (g.ragged > 0 ? 1 : 0)) * (g.N / 256);
     const int grid = T >= 256 ? 256 : T;
     MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p8_kernel<EPI>), Q256_LDS));
     hipLaunchKernelGGL((gemm256p8_kernel<EPI>), dim3(grid), dim3(512), Q256_LDS, st, g);
@@ -517,6 +657,10 @@ static int launch_gemm256p8(hipStream_t st, int epi, Gemm8Args g) {
     if (epi == MMISS_EPI8_QGELU_MXFP8 && (!g.out_scale || g.ld_os < mx_scale_row_bytes(g.N)))
         MM_FAIL(MMISS_ERR_ARG, "gemm256p8: the MXFP8 epilogue needs out_scale with >= %d bytes per row", mx_scale_row_bytes(g.N));
     if (g.m_fast == 0) g.m_fast = mmiss_option("gemm_p256_band", 8);  // row blocks per band of the global tile order
+    // a last row block with at most 128 valid rows goes through the register-streamed pass (option gemm_p256_ragged = 0: a tile)
+    g.ragged = 0;
+    if (g.M >= 512 && g.m_valid > g.M - 256 && g.m_valid <= g.M - 128 && mmiss_option("gemm_p256_ragged", 1) != 0)
+        g.ragged = g.m_valid - (g.M - 256);
     static const char* names[] = {"gemm_fp8_bias_p256", "gemm_fp8_qgelu_mx_p256", "", "gemm_fp8_bias_resid16_p256"};
     const int mv = g.m_valid < g.M ? g.m_valid : g.M;
     const double out_b = epi == MMISS_EPI8_BIAS_BF16 ? 2.0 : (epi == MMISS_EPI8_QGELU_MXFP8 ? 1.0 : 4.0);

@@ -245,11 +245,30 @@ def test_persistent_fp8_gemm_equals_the_tile_kernel_bit_for_bit(env, epi, M, mv,
             _lib.check(lib.mmiss_dbg_gemm8(0, None, epi, bm, A8.data_ptr(), As.data_ptr(), W8.data_ptr(), ws.data_ptr(),
                                            bias.data_ptr(), out.data_ptr(), osc.data_ptr(), M, N, K))
         torch.cuda.synchronize()
-        outs.append((out[:mv].view(torch.uint8) if epi != 1 else out[:mv], osc[:mv]))
-    assert torch.equal(outs[0][0], outs[1][0]), "output bytes differ in %d places" % int((outs[0][0] != outs[1][0]).sum())
+        outs.append((out[:mv], osc[:mv]))
+    # A last row block with at most 128 valid rows (configs[4]: 32 896 = 128 x 256 + 128) is not a tile of the persistent kernel:
+    # all workgroups compute it in front of the tile stream, a unit's K-tiles dealt over eight waves — eight partial sums
+    # instead of one chain, so those rows may differ in the last bits of the f32 sums. Everything else: equal bytes.
+    ragged = M - 256 < mv <= M - 128
+    mt = M - 256 if ragged else mv
+    (o_t, s_t), (o_p, s_p) = outs
+    as_bytes = (lambda t: t.view(torch.uint8)) if epi != 1 else (lambda t: t)
+    assert torch.equal(as_bytes(o_t[:mt]), as_bytes(o_p[:mt])), "output bytes differ in %d places" % int((as_bytes(o_t[:mt]) != as_bytes(o_p[:mt])).sum())
     if epi == 1:
-        assert torch.equal(outs[0][1], outs[1][1])
-        assert int((outs[1][0] != 0).sum()) > 0.3 * mv * N
+        assert torch.equal(s_t[:mt], s_p[:mt])
+        assert int((o_p != 0).sum()) > 0.3 * mv * N
+    if ragged:
+        if epi == 1:
+            back_t = fo.mx_dequantize(o_t[mt:].cpu().numpy(), fo.unpermute_scales(s_t[mt:].cpu().numpy(), N))
+            back_p = fo.mx_dequantize(o_p[mt:].cpu().numpy(), fo.unpermute_scales(s_p[mt:].cpu().numpy(), N))
+            assert (as_bytes(o_t[mt:]) != as_bytes(o_p[mt:])).float().mean() < 2e-3          # a rounding boundary crossed here and there
+            gmax = np.abs(back_t).reshape(back_t.shape[0], -1, 64).max(axis=2).repeat(64, axis=1)
+            assert (np.abs(back_t - back_p) <= gmax * 2.0 ** -3 + 1e-6).all()                    # ... by one e4m3 step at most
+        else:
+            a, b = o_t[mt:].float(), o_p[mt:].float()
+            # <= 1 bf16 ulp, or the last bits of an f32 sum whose terms cancel (relative to the largest output of the block)
+            assert (a != b).float().mean() < 2e-3
+            assert bool(((a - b).abs() <= a.abs() * 2.0 ** -7 + 2e-5 * float(a.abs().max())).all())
 
 
 def _fp8_vs_bf16_vs_oracle(shape, seed, B_img, B_txt, T):
@@ -422,7 +441,9 @@ def test_longclip_l14_full_depth_vision_bf16_and_fp8(env):
     assert kern.get("gemm_fp8_bias", 0) == 24 and kern.get("gemm_fp8_bias_resid", 0) == 23, kern
     # round 4: at the config's batch the attention output leaves its kernel as MXFP8 and the out-projection is an fp8 GEMM
     # too (23 layers; the pruned last layer keeps the bf16 form): 23 FC2 + 23 out-projections on gemm_fp8_bias_resid16
-    assert kern128.get("gemm_fp8_bias", 0) == 24 and kern128.get("gemm_fp8_bias_resid16", 0) == 46, kern128
+    # round 5: all four on the persistent 256 x 256 kernel (gemm_fp8_p256.h); the pruned last layer's FC1 / FC2 are skinny bf16 GEMMs
+    assert kern128.get("gemm_fp8_bias_p256", 0) == 24 and kern128.get("gemm_fp8_bias_resid16_p256", 0) == 46, kern128
+    assert kern128.get("gemm_fp8_qgelu_mx_p256", 0) == 23 and not any(k in kern128 for k in ("gemm_fp8_bias", "gemm_fp8_bias_resid16")), kern128
     assert kern128.get("attention_mx", 0) == 23 and kern128.get("attention", 0) == 1, kern128
     assert d16.max() < COS_TOL and d16_128.max() < COS_TOL, (d16, d16_128)
     assert d8.max() < COS_TOL and d8_128.max() < COS_TOL, (d8, d8_128)
@@ -440,5 +461,5 @@ def test_longclip_l14_full_depth_vision_bf16_and_fp8(env):
         enc.close()
     d8_b = 1 - _cos(out8_b[:8], ref)
     print("   out-projection bf16 (fp8_outproj = 0): fp8 bs 128 (first 8) %.2e" % d8_b.max())
-    assert kern_b.get("gemm_fp8_bias_resid16", 0) == 23 and kern_b.get("attention_mx", 0) == 0, kern_b
+    assert kern_b.get("gemm_fp8_bias_resid16_p256", 0) == 23 and kern_b.get("attention_mx", 0) == 0, kern_b
     assert d8_b.max() < COS_TOL
