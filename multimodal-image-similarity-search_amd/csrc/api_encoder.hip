@@ -650,11 +650,14 @@ int finish_call(mmiss_encoder* e, hipStream_t st, bool must_sync) {
 
 // Resize + centre-crop images b0 .. b0+nb-1 of a raw RGB8 blob into dst_dev (uint8 [nb,S,S,3], device), on st.
 // `staged` != null: the chunk's byte range [its lo, its hi) of the host blob already sits at `staged` in HBM.
-// host bytes -> device on `stream`: through the handle's pinned ring from 4 MB on (option pinned_stage = 0: plain
-// hipMemcpyAsync from the caller's pageable memory, the round-4 form; stage_threads: host threads per block, default
-// min(8, hardware threads / 2)); small copies go directly — a single request must not pay for waking the copy threads
+// host bytes -> device on `stream`. Default: hipMemcpyAsync from the caller's pageable memory. Option pinned_stage = 1: through
+// the handle's ring of pinned blocks filled by parallel host copies (host_stager.h; stage_threads, stage_block_mb) from 4 MB
+// on. Measured on the MI355X box (tools/stage_probe.py, profiles/host_staging_r05.txt): once a call holds several batches, so
+// that batch k + 1 crosses PCIe while batch k is computed, BOTH forms run at what the link gives — 40-45 GB/s, 4-16 copy
+// threads, 8-64 MB blocks alike (f32 pixels 41.6 vs 40.5 GB/s, RGB8 uploads 44.5 vs 44.8) — so the ring is off by default;
+// the 26 GB/s of round 4's `pcie_inclusive` was one batch per call: copy and compute in series, not a slow copy.
 static int enc_h2d(mmiss_encoder* enc, void* dst, const void* src, size_t bytes, hipStream_t stream) {
-    if (bytes >= (size_t)(4 << 20) && mmiss_option("pinned_stage", 1) != 0) {
+    if (bytes >= (size_t)(4 << 20) && mmiss_option("pinned_stage", 0) != 0) {
         if (!enc->stager.slot_bytes) {
             const int hw = (int)std::thread::hardware_concurrency();
             int nthr = mmiss_option("stage_threads", 0);

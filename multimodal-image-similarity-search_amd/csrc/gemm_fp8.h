@@ -532,10 +532,11 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
 
 // d = 1024 (ViT-L/14): SIXTEEN consecutive columns per lane — two 16-byte loads, ONE 16-byte store per row and lane (the
 // 8-column form stores 8 bytes: half-width store instructions), a 32-column block = 2 lanes: one xor-shuffle.
+template <int RW>   // rows per wave, all of them loaded before the first is used (4: round 4; 8: A/B of round 5, option ln_mxfp8_wide = 3)
 __global__ __launch_bounds__(256) void layernorm16_mxfp8_1024_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, uint8_t* __restrict__ out,
                                                                      uint8_t* __restrict__ out_scale, int M, int ld_os, float eps) {
-    constexpr int D = 1024, RW = 4;
+    constexpr int D = 1024;
     const int lane = threadIdx.x & 63;
     const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
     if (r0 >= M) return;
@@ -604,7 +605,10 @@ static int launch_layernorm_mxfp8(hipStream_t st, const void* x, bool x_bf16, co
     if (x_bf16 && (d == 512 || d == 1024) && mmiss_option("ln_mxfp8_wide", 1) != 0) {
         const int grid = (M + 15) / 16;
         if (d == 1024 && mmiss_option("ln_mxfp8_wide", 1) == 1)
-            hipLaunchKernelGGL(layernorm16_mxfp8_1024_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
+            hipLaunchKernelGGL(layernorm16_mxfp8_1024_kernel<4>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
+                               beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
+        else if (d == 1024 && mmiss_option("ln_mxfp8_wide", 1) == 3)
+            hipLaunchKernelGGL(layernorm16_mxfp8_1024_kernel<8>, dim3((M + 31) / 32), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
                                beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
         else if (d == 1024)   // (option ln_mxfp8_wide = 2: the 8-columns-per-lane form, A/B)
             hipLaunchKernelGGL(layernorm16_mxfp8_wide_kernel<2>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
         if (ncol == 8) ragged_units(std::integral_constant<int, 8>{});
         else if (ncol == 4) ragged_units(std::integral_constant<int, 4>{});
         else if constexpr (EPI != MMISS_EPI8_QGELU_MXFP8) ragged_units(std::integral_constant<int, 2>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (no wait for the stores: they are older than every operation of the tile stream, so they retire first and the counted
+        // waits never see them; the barrier above is what hands `red` to the staging slots)
     }
 
     // ---- tile list (gemm256p_kernel: rounds of G tiles of a banded global order; a last round of at most G/2 tiles in halves)
