@@ -68,6 +68,7 @@ struct Tower {
     DevBuf x, h, qkv, ctx, u, pooled, proj_out, pool_row, out_stage, taps;
     int pool_B = -1, pool_T = -1;   // vision: pool_row currently holds b * pool_T for b < pool_B (written once per shape)
     bool embed_stats = false;       // this call's embedding stage already left xb + row statistics (layernorm_stats_kernel)
+    bool embed_stats16 = false;     // ... xb + the 16-column statistics of the one-request mode (prelayernorm_skinny_kernel)
     DevBuf xc, hc, ctxc, uc;  // compact [Bp, *] buffers of the pooled rows (last-layer pruning)
     DevBuf stats;             // [Mp][hidden/64][2] partial row (sum, sumsq) for the LayerNorm-fused GEMMs
     DevBuf stats_final;       // [Mp][2] finished (mean, rstd): hidden > 768 on the persistent GEMM (ln_finalize_kernel)
@@ -256,6 +257,16 @@ int ensure_tower_ws(mmiss_encoder* e, Tower& tw, int max_batch, int proj_dim) {
     return MMISS_OK;
 }
 
+// One request at a time: all four GEMMs of a layer on the weight-streaming skinny kernel with the LayerNorm folded in (run_layers)
+static bool skinny_fold_ok(const Tower& tw, int M) {
+    const int d = tw.hidden;
+    if (M > 128 || (d % 128) != 0 || mmiss_option("skinny_fold", 1) == 0) return false;
+    GemmEpi probe{};
+    probe.stats16 = 1;
+    return gemm_skinny_ok(MMISS_EPI_LNFOLD_BF16, M, 3 * d, d, probe) && gemm_skinny_ok(MMISS_EPI_LNFOLD_QGELU_BF16, M, tw.mlp, d, probe) &&
+           gemm_skinny_ok(MMISS_EPI_BIAS_RESID_F32, M, d, d, probe) && gemm_skinny_ok(MMISS_EPI_BIAS_RESID_F32, M, d, tw.mlp, probe);
+}
+
 // the transformer stack shared by both towers; x holds the embeddings on entry
 // LayerNorm placement for a call of M token rows: 0 separate kernels, 1 staged (experiments), 2 folded into the GEMMs
 static int pick_ln_mode(const mmiss_encoder* e, const Tower& tw, int M, bool& fp8) {
@@ -375,15 +386,11 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // into the QKV / FC1 weights there as well — the skinny residual GEMMs leave a bf16 copy of the new rows and their
     // partial statistics per 16 columns, the skinny QKV / FC1 GEMMs apply (mean, rstd) in their epilogue. 24 of the ~99
     // launches of a ViT-B/32 request disappear. Option skinny_fold = 0 keeps the LayerNorm kernels.
-    bool sfold = false;
-    if (plain && !fp8 && M <= 128 && (d % 128) == 0 && mmiss_option("skinny_fold", 1) != 0) {
-        GemmEpi probe{};
-        probe.stats16 = 1;
-        sfold = gemm_skinny_ok(MMISS_EPI_LNFOLD_BF16, M, 3 * d, d, probe) && gemm_skinny_ok(MMISS_EPI_LNFOLD_QGELU_BF16, M, tw.mlp, d, probe) &&
-                gemm_skinny_ok(MMISS_EPI_BIAS_RESID_F32, M, d, d, probe) && gemm_skinny_ok(MMISS_EPI_BIAS_RESID_F32, M, d, tw.mlp, probe);
-    }
+    const bool sfold = plain && !fp8 && skinny_fold_ok(tw, M);
     const int parts = d / 64;
-    if (sfold) {
+    const bool have_embed_stats16 = tw.embed_stats16;   // (the one-request embedding stage already wrote xb + the 16-column statistics)
+    tw.embed_stats16 = false;
+    if (sfold && !have_embed_stats16) {
         MM_PROF("row_stats", st, 3.0 * M * d, 6.0 * M * d);
         hipLaunchKernelGGL(skinny_row_stats16_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), tw.stats.as<float>(),
                            tw.xb.as<uint16_t>(), M, d);
@@ -572,8 +579,14 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
     const int bm_p = gemm_pick_variant(Mpatch, d);
     const int Mpp = (int)round_up(Mpatch, bm_p % 1000);
     MM_TRY(launch_im2col(st, pix_dev, src_u8, e->patches.p, B, S, P, e->Kp));
-    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, st, tw.x.as<float>(),
-                       e->cls.as<float>(), tw.pos.as<float>(), B, tw.T, d);
+    // One request at a time (the layers will run in the skinny folded mode): CLS rows, pre_layrnorm and the mode's entry
+    // statistics are ONE launch behind the patch GEMM (prelayernorm_skinny_kernel) instead of three. Option embed_fused = 0: off.
+    bool fp8_l = false;
+    const bool fused_embed = !e->record_taps && d <= 1024 && (d % 16) == 0 && pick_ln_mode(e, tw, B * tw.T, fp8_l) == 0 && !fp8_l &&
+                             skinny_fold_ok(tw, B * tw.T) && mmiss_option("embed_fused", 1) != 0;
+    if (!fused_embed)
+        hipLaunchKernelGGL(cls_rows_kernel, dim3((B * d + 255) / 256), dim3(256), 0, st, tw.x.as<float>(),
+                           e->cls.as<float>(), tw.pos.as<float>(), B, tw.T, d);
     GemmEpi ep{};
     ep.out = tw.x.p; ep.aux = tw.pos.as<float>(); ep.ldo = d; ep.m_valid = Mpatch; ep.p0 = e->G * e->G; ep.p1 = tw.T;
     if (gemm_splitk_candidate((int64_t)(Mpp / (bm_p % 1000)) * (d / GEMM_BN), e->Kp)) {
@@ -597,7 +610,14 @@ int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B
         const bool want = !e->record_taps && d % 128 == 0 &&
                           (mode == 2 || (mode == 0 && M >= mmiss_option("ln_fold_min_rows", 6000))) &&
                           mmiss_option("prelayernorm_stats", 1) != 0;
-        if (want) {
+        if (fused_embed) {
+            MM_PROF("layernorm", st, 12.0 * M * d, (double)M * d * 10);
+            hipLaunchKernelGGL(prelayernorm_skinny_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), e->cls.as<float>(),
+                               tw.pos.as<float>(), e->pre_g.as<float>(), e->pre_b.as<float>(), tw.xb.as<uint16_t>(), tw.stats.as<float>(),
+                               M, tw.T, d, e->cfg.ln_eps);
+            MM_HIP(hipGetLastError());
+            tw.embed_stats16 = true;
+        } else if (want) {
             MM_PROF("layernorm", st, 10.0 * M * d, (double)M * d * 10);
             hipLaunchKernelGGL(layernorm_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.x.as<float>(), e->pre_g.as<float>(),
                                e->pre_b.as<float>(), tw.xb.as<uint16_t>(), tw.stats.as<float>(), M, d, d / 64, e->cfg.ln_eps);

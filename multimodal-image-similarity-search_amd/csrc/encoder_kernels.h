@@ -76,6 +76,75 @@ __global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__
     }
 }
 
+// One request at a time (round 5): the vision tower's CLS rows, pre_layrnorm and the entry statistics of the skinny folded mode
+// in ONE launch instead of three (cls_rows_kernel, layernorm_kernel in place, skinny_row_stats16_kernel). One wave per token row:
+// row t = 0 of an image is class_embedding + position_embedding[0] (HF:modeling_clip.py:213-216) computed here, the others
+// were written by the patch GEMM; LayerNorm with layernorm_kernel's arithmetic (two-pass mean / variance, the same lane
+// layout and summation order), the result written back as the f32 residual stream, as its bf16 copy, and as the (sum, sumsq)
+// of every 16-column slice (four consecutive lanes: skinny_row_stats16_kernel's order) — the same bits as the three kernels.
+__global__ __launch_bounds__(256) void prelayernorm_skinny_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                                  const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, uint16_t* __restrict__ xb,
+                                                                  float* __restrict__ stats, int M, int T, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const bool is_cls = (r % T) == 0;
+    float* xr = x + (size_t)r * d;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < d) {
+            if (is_cls) v[i] = *reinterpret_cast<const f32x4*>(cls + c) + *reinterpret_cast<const f32x4*>(pos + c);
+            else v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+        }
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (i * 64 + lane) * 4;   // (wave-uniform validity per i: d % 256 == 0 is not required, d % 16 == 0 is)
+        f32x4 y = {0.f, 0.f, 0.f, 0.f};
+        if (c < d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            *reinterpret_cast<f32x4*>(xr + c) = y;
+            u32x2 pk;
+            pk[0] = pack_bf16x2(y[0], y[1]);
+            pk[1] = pack_bf16x2(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(xb + (size_t)r * d + c) = pk;
+        }
+        float ss = (y[0] + y[1]) + (y[2] + y[3]);
+        float qq = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+        ss += __shfl_xor(ss, 1); qq += __shfl_xor(qq, 1);
+        ss += __shfl_xor(ss, 2); qq += __shfl_xor(qq, 2);
+        if (c < d && (lane & 3) == 0) {
+            float* o = stats + ((size_t)r * (d >> 4) + (c >> 4)) * 2;
+            o[0] = ss;
+            o[1] = qq;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K9: text embeddings.  x[b*T+t][:] = token_embedding[ids[b,t]] + position_embedding[t]
 // (HF:modeling_clip.py:226-256). Also finds the pooled position per row: first id == eos_id, or

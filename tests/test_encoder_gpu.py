@@ -377,6 +377,16 @@ def test_single_request_runs_without_layernorm_launches(b32):
     out1, k1 = kernels_of(lambda: enc.encode_image(px[:1]))
     assert k1.get("gemm_skinny_lnfold_bias", 0) == 12 and k1.get("gemm_skinny_lnfold_qgelu", 0) == 11, k1
     assert k1.get("layernorm", 0) <= 4, k1          # pre-LN, the pruned last layer's LN2, the head — no per-layer launches
+    # round 5: CLS rows + pre-LN + the mode's entry statistics are ONE launch (prelayernorm_skinny_kernel): no row_stats launch,
+    # and the same bits as the three separate kernels (option embed_fused = 0)
+    assert "row_stats" not in k1, k1
+    _lib.set_option("embed_fused", 0)
+    try:
+        out1_unfused, k1u = kernels_of(lambda: enc.encode_image(px[:1]))
+    finally:
+        _lib.set_option("embed_fused", 1)
+    assert k1u.get("row_stats", 0) == 1, k1u
+    np.testing.assert_array_equal(out1, out1_unfused)
     out2 = enc.encode_image(px[1:2])
     out_t, kt = kernels_of(lambda: enc.encode_text(ids))
     assert kt.get("gemm_skinny_lnfold_bias", 0) == 12, kt
