@@ -214,6 +214,38 @@ def test_l14_width_fp8_outlier_hidden_channels():
         assert max(v) < COS_TOL, (prec, v)
 
 
+def test_l14_full_depth_outlier_channels_measured():
+    """The same +300 / -180 residual channels through ALL 24 layers of the ViT-L/14 tower at the config's batch (128 images,
+    first 4 checked): the bf16 setting must hold the 1e-3 bar; the fp8 setting is MEASURED and printed — every e4m3 rounding
+    of a weight column that meets a channel of magnitude 300 is amplified 300-fold against the other 1022 columns, and 24
+    layers of it add up — and held to a documented, looser bound: a checkpoint with such channels should run the vision
+    tower under set_precision("bf16"). Seeded Gaussian weights without outliers: 5.5e-4 (test_fp8_gpu.py)."""
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+    import dataclasses
+
+    s = dataclasses.replace(co.LONGCLIP_L14, t_layers=1, t_vocab=1000, eos_token_id=999)
+    W = co.init_weights(s, seed=71)
+    pos = W["vision_model.embeddings.position_embedding.weight"].copy()
+    pos[:, 31] += 300.0
+    pos[:, 700] -= 180.0
+    W["vision_model.embeddings.position_embedding.weight"] = pos
+    rng = np.random.Generator(np.random.Philox(72))
+    px = rng.standard_normal((128, 3, 224, 224), dtype=np.float32)
+    ref = co.embed_images(px[:4], W, s)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=128, max_batch_text=2)
+    enc.load_state_dict(W)
+    d = {}
+    for prec in ("bf16", "fp8"):
+        enc.set_precision(prec)
+        d[prec] = float((1 - _cos(enc.encode_image(px)[:4], ref)).max())
+    enc.close()
+    print("outlier channels, ViT-L/14 at FULL depth (24 layers), 128 per call: 1 - cos vs oracle bf16 %.2e, fp8 %.2e" % (d["bf16"], d["fp8"]))
+    assert d["bf16"] < COS_TOL, d
+    assert d["fp8"] < 5e-3, d     # (measured, not the parity bar: see the docstring)
+
+
 def test_drill_set_config0_on_the_gpu(b32_256):
     """BASELINE configs[0]: the reference's six sample images + the query 'red drill' (surrogate ids), seeded ViT-B/32
     weights, through the real towers and the real index: embeddings vs the HF vectors, the 6 x 6 cosine matrix, the
