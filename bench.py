@@ -321,7 +321,7 @@ def main():
         # value is the rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE measurement of the SAME command taken in
         # separate --pmc passes and kept in profiles/ — i.e. NOT measured in this run
         traffic, traffic_src = None, None
-        for fn in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for fn in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
                     tj = json.load(f)
@@ -830,6 +830,20 @@ def bench_retrieval(args, torch, dist, np, dev, rank, world, local_rank, FlatInd
             sg_ms = sg["ms"] / sg["launches"]
             tfl = sg["flops"] / sg["ms"] / 1e9   # the filtered pass covers 15/16 of the rows; its own flops
             entry["score_gemm"] = {"avg_ms": round(sg_ms, 4), "tflops": round(tfl, 1), "mfma_frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4)}
+            # fabric bytes per launch of the strip score GEMM from the round's PMC passes over tools/retrieval_profile.py (the
+            # same 10M x 512 f16 index and Q = 1024; counters cannot be read from inside this process), against the index bytes
+            # one pass must read
+            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_traffic_retrieval.json")
+            if world == 1 and N == 10_000_000 and Q == 1024 and os.path.exists(tfile):
+                try:
+                    tj = json.load(open(tfile)).get("score_gemm_f16_strip") or {}
+                    if tj.get("traffic_bytes_all_launches"):
+                        per_batch = tj["traffic_bytes_all_launches"] / 6.0   # tools/retrieval_profile.py: six Q = 1024 batches (sample + filtered pass each)
+                        entry["score_gemm"]["traffic_bytes_per_batch"] = int(per_batch)
+                        entry["score_gemm"]["traffic_vs_index_bytes"] = round(per_batch / (N * D * 2.0), 3)
+                        entry["score_gemm"]["traffic_source"] = "profiles/r05_traffic_retrieval.json (separate rocprofv3 --pmc passes over tools/retrieval_profile.py, not this run)"
+                except Exception:
+                    pass
         if scan:
             scan_ms = scan["ms"] / scan["launches"]
             gbs = per * D * 2 / scan_ms / 1e6

@@ -78,7 +78,9 @@ def main(fetch_csv, write_csv, out):
         fb = 2.0 * 1024.0 * sum(fv) / len(fv)
         wb = 1024.0 * sum(wv) / len(wv)
         ent = {"symbol_regex": pat, "launches_sampled": len(fv), "fetch_bytes_corrected": round(fb),
-               "write_bytes": round(wb), "traffic_bytes": round(fb + wb)}
+               "write_bytes": round(wb), "traffic_bytes": round(fb + wb),
+               # all sampled launches together (classes whose launches differ in size: the score GEMM's sample and filtered pass)
+               "traffic_bytes_all_launches": round(2.0 * 1024.0 * sum(fv) + 1024.0 * sum(wv))}
         if cls in ALGORITHMIC:
             ent["algorithmic_bytes_avg"] = ALGORITHMIC[cls]
             ent["ratio_to_algorithmic"] = round((fb + wb) / ALGORITHMIC[cls], 3)
