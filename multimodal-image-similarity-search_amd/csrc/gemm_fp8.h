@@ -532,7 +532,9 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
 
 // d = 1024 (ViT-L/14): SIXTEEN consecutive columns per lane — two 16-byte loads, ONE 16-byte store per row and lane (the
 // 8-column form stores 8 bytes: half-width store instructions), a 32-column block = 2 lanes: one xor-shuffle.
-template <int RW>   // rows per wave, all of them loaded before the first is used (4: round 4; 8: A/B of round 5, option ln_mxfp8_wide = 3)
+// PACKS (A/B of round 5, option ln_mxfp8_wide = 5): the row's 32 scale bytes leave as eight dwords from eight lanes (four
+// lane gathers per row) instead of 32 single-byte stores from 32 lanes
+template <int RW, bool PACKS = false>   // RW: rows per wave, all of them loaded before the first is used (4: round 4; 8: A/B of round 5, option ln_mxfp8_wide = 3)
 __global__ __launch_bounds__(256) void layernorm16_mxfp8_1024_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, uint8_t* __restrict__ out,
                                                                      uint8_t* __restrict__ out_scale, int M, int ld_os, float eps) {
@@ -593,7 +595,18 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_1024_kernel(const uint1
 #pragma unroll
             for (int i = 0; i < 4; ++i) pk[i] = pack_fp8x4(y[4 * i] * inv, y[4 * i + 1] * inv, y[4 * i + 2] * inv, y[4 * i + 3] * inv);
             *reinterpret_cast<u32x4*>(out + (size_t)r * D + c) = pk;
-            if ((lane & 1) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
+            if constexpr (!PACKS) {
+                if ((lane & 1) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
+            }
+        }
+        if constexpr (PACKS) {
+            // dword t = (group G = t >> 2, k-block c = t & 3) of the permuted row: bytes t' = 0..3 are the scales of column blocks
+            // 16 G + 4 t' + c, held by lanes 2 (16 G + 4 t' + c) — gathered by lane t (wave-uniform control flow: every lane shuffles)
+            const int t = lane & 7, srcl = 32 * (t >> 2) + 2 * (t & 3);
+            uint32_t dw = 0;
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) dw |= (uint32_t)(__shfl(e8, srcl + 8 * tp) & 0xff) << (8 * tp);
+            if (r < M && lane < 8) *reinterpret_cast<uint32_t*>(out_scale + (size_t)r * ld_os + 4 * lane) = dw;
         }
     }
 }
@@ -606,6 +619,9 @@ static int launch_layernorm_mxfp8(hipStream_t st, const void* x, bool x_bf16, co
         const int grid = (M + 15) / 16;
         if (d == 1024 && mmiss_option("ln_mxfp8_wide", 1) == 1)
             hipLaunchKernelGGL(layernorm16_mxfp8_1024_kernel<4>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
+                               beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
+        else if (d == 1024 && mmiss_option("ln_mxfp8_wide", 1) == 5)
+            hipLaunchKernelGGL((layernorm16_mxfp8_1024_kernel<4, true>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
                                beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
         else if (d == 1024 && mmiss_option("ln_mxfp8_wide", 1) == 3)
             hipLaunchKernelGGL(layernorm16_mxfp8_1024_kernel<8>, dim3((M + 31) / 32), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
