@@ -2,6 +2,7 @@
 // SURVEY.md §2.2). Each kernel cites the HF arithmetic it restates.
 #pragma once
 #include "common.h"
+#include "attention_stream.h"
 
 // ------------------------------------------------------------------------------------------------
 // K1 prologue: patchify.  pixels f32 [B,3,S,S] -> patches bf16 [B*G*G, Kp], k = c*P*P + ky*P + kx
@@ -997,6 +998,10 @@ static int launch_attention_long_t(hipStream_t st, const void* qkv, void* ctx, u
 
 template <bool CAUSAL, bool MXOUT>
 static int launch_attention_long(hipStream_t st, const void* qkv, void* ctx, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
+    // round 5: the ViT-L/14 regime on the persistent streaming kernel (attention_stream.h); option attention_stream = 0: this kernel
+    if constexpr (!CAUSAL)
+        if (attention_stream_ok(B, T, H, false) && mmiss_option("attention_stream", 1))
+            return launch_attention_stream<MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, H);
     switch ((T + 31) / 32) {
         case 5: return launch_attention_long_t<5, CAUSAL, MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, T, H);
         case 6: return launch_attention_long_t<6, CAUSAL, MXOUT>(st, qkv, ctx, ctx8, ctxs, ld_s, B, T, H);

@@ -1,26 +1,27 @@
-"""Timeline of ONE steady-state request (image encode at batch 1 + top-10) from a rocprofv3 --kernel-trace CSV of
-tools/single_request.py: every kernel of the request in launch order with its duration and the idle time before it."""
+#!/usr/bin/env python3
+"""Timeline of ONE steady-state request out of a rocprofv3 --kernel-trace of tools/single_request.py: per kernel its duration and
+the gap behind its predecessor. usage: request_timeline.py <kernel_trace.csv> [launches per request, default: detected]"""
 import csv
+import re
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1]))]
+rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a request starts at the patch-embedding kernel; take the one in the middle of the trace that is followed by a query
-starts = [i for i, r in enumerate(rows) if "patch" in r["Kernel_Name"].lower() or "im2col" in r["Kernel_Name"].lower()]
-if not starts:
-    starts = [0]
-pick = starts[min(len(starts) - 1, int(sys.argv[2]) if len(sys.argv) > 2 else 150)]
-nxt = [s for s in starts if s > pick]
-end = nxt[0] if nxt else len(rows)
-t0 = int(rows[pick]["Start_Timestamp"])
+names = [r["Kernel_Name"] for r in rows]
+# a request starts at im2col
+starts = [i for i, n in enumerate(names) if "im2col" in n]
+mid = starts[len(starts) // 3]
+nxt = starts[len(starts) // 3 + 1]
+seg = rows[mid:nxt]
+tot_d = tot_g = 0.0
 prev = None
-busy = 0.0
-for r in rows[pick:end]:
+short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:64]
+for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    busy += (e - s) / 1e3
-    print("%8.1f us  +%6.2f gap  %7.2f us  %s  grid %s wg %s" % ((s - t0) / 1e3, 0.0 if prev is None else (s - prev) / 1e3, (e - s) / 1e3,
-                                                    r["Kernel_Name"][:70], r.get("Grid_Size_X", "?"), r.get("Workgroup_Size_X", "?")))
+    gap = (s - prev) / 1e3 if prev else 0.0
+    print(f"{short(r['Kernel_Name']):64s} {(e - s) / 1e3:6.2f} us  gap {gap:6.2f}")
+    tot_d += (e - s) / 1e3
+    tot_g += gap
     prev = e
-print("request: %d kernels, span %.1f us, busy %.1f us" % (end - pick, (prev - t0) / 1e3, busy))
-if nxt:
-    print("next request starts %.1f us after this one's last kernel ended" % ((int(rows[nxt[0]]["Start_Timestamp"]) - prev) / 1e3))
+print(f"{len(seg)} launches, kernels {tot_d:.1f} us + gaps {tot_g:.1f} us = {tot_d + tot_g:.1f} us "
+      f"(first start to last end {(int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e3:.1f})")
