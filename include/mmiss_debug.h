@@ -88,6 +88,22 @@ int mmiss_dbg_attention_mx(int device, void* hip_stream, const void* qkv, void* 
 /* epi: 0 out bf16 = acc * wscale[n] + bias[n]; 1 out e4m3 + out_scale = mx(quick_gelu(.)); 2 out f32 += . ; bm = 128 | 160 | 192 */
 int mmiss_dbg_gemm8(int device, void* hip_stream, int epi, int bm, const void* A8, const void* As, const void* W8,
                     const float* wscale, const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K);
+/* the persistent fp8 GEMM's extensions of round 5 (gemm_fp8_p256.h; M % 256 == 0, rows >= m_valid are padding):
+ * xt = 1 (epi 0 / 1, K = 1024): LayerNorm folded in — A8 / As = the RAW bf16 rows x16 [M, K] as MXFP8, W8 the gamma-folded weights,
+ *        bias = b', c16 = f16 [N] row sums of the dequantised W8, ln_stats = f32 [M][4][2] (sum, sumsq) per 256-column quarter of
+ *        the rows of x16: out = rstd (acc wscale - mean c) + b' (then QuickGELU -> MXFP8 for epi 1);
+ * xt = 2 (epi 3, N = 1024): out bf16 += ..., and the new rows also as MXFP8 (q_out e4m3 [M, N], q_scale permuted E8M0) with
+ *        stats_out f32 [M][N/256][2] of the tile rows (the rows of a ragged last block get none). */
+int mmiss_dbg_gemm8_xt(int device, void* hip_stream, int epi, int xt, const void* A8, const void* As, const void* W8,
+                       const float* wscale, const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K,
+                       int32_t m_valid, const void* c16, const float* ln_stats, const void* x16, float ln_eps, void* q_out,
+                       void* q_scale, float* stats_out);
+/* bf16 rows [M, 1024] -> MXFP8 (raw) + (sum, sumsq) per 256-column quarter, f32 [M][4][2]: the entry of the folded fp8 mode */
+int mmiss_dbg_quant16_mxfp8_stats(int device, void* hip_stream, const void* x_bf16, void* out8, void* out_scale, float* stats,
+                                  int32_t M, int32_t d);
+/* e4m3 codes + per-channel scales of bf16 weights [N, K] and c16 = f16 row sums of the dequantised codes */
+int mmiss_dbg_quantize_weights_fp8_csum(int device, void* hip_stream, const void* w_bf16, void* w8, float* scale, void* c16,
+                                        int32_t N, int32_t K);
 int mmiss_dbg_gemm8_time(int device, int epi, int bm, const void* A8, const void* As, const void* W8, const float* wscale,
                          const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K, int32_t iters,
                          float* ms_per_launch);

@@ -113,6 +113,9 @@ SIGNATURES = {
     "mmiss_dbg_layernorm16_mxfp8": (_I, [_I, _P, _P, _P, _P, _P, _P, _I32, _I32, C.c_float]),
     "mmiss_dbg_attention_mx": (_I, [_I, _P, _P, _P, _P, _I32, _I32, _I32]),
     "mmiss_dbg_gemm8": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32]),
+    "mmiss_dbg_gemm8_xt": (_I, [_I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "mmiss_dbg_quant16_mxfp8_stats": (_I, [_I, _P, _P, _P, _P, _P, _I32, _I32]),
+    "mmiss_dbg_quantize_weights_fp8_csum": (_I, [_I, _P, _P, _P, _P, _P, _I32, _I32]),
     "mmiss_dbg_gemm8_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.POINTER(C.c_float)]),
     "mmiss_dbg_gemm_split_time": (_I, [_I, _I, _I, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.POINTER(C.c_float)]),
 }

@@ -55,6 +55,7 @@ struct LayerW {
     DevBuf wqkv_f, cqkv, bqkv_f, w1_f, c1, b1_f;  // LayerNorm folded into the QKV / FC1 weights (finalize)
     DevBuf wqkv8, sqkv, w1_8, s1, w2_8, s2;       // fp8 path: e4m3 weights + per-output-channel f32 scales
     DevBuf wo8, so;                               // ... of the out-projection (used when the attention output is MXFP8)
+    DevBuf wqkv8f, sqkvf, cqkv16, w1_8f, s1f, c1_16;  // fp8 path with the LayerNorm folded in (hidden 1024): e4m3 of the gamma-folded weights, scales, f16 row sums
 };
 
 struct Tower {
@@ -307,8 +308,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         if (p8_min == 0 || !gemm256p8_ok(epi, (int)round_up(M, 256), N, K)) return false;
         return (int64_t)(round_up(M, 256) / 256) * (N / 256) >= (p8_min > 1 ? p8_min : 256);
     };
-    auto gemm8_any = [&](int epi, int bm, Gemm8Args g8) -> int {   // g8.M unset: padded here to the kernel's tile height
-        if (p8(epi, g8.N, g8.K)) { g8.M = (int)round_up(M, 256); return launch_gemm256p8(st, epi, g8); }
+    auto gemm8_any = [&](int epi, int bm, Gemm8Args g8, int xt = 0) -> int {   // g8.M unset: padded here to the kernel's tile height
+        if (xt != 0 || p8(epi, g8.N, g8.K)) { g8.M = (int)round_up(M, 256); return launch_gemm256p8(st, epi, g8, xt); }
         g8.M = (int)round_up(M, bm % 1000);
         return launch_gemm8(st, epi, bm, g8);
     };
@@ -404,11 +405,48 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
                            (fold || resid16) ? tw.xb.as<uint16_t>() : nullptr, M, d, parts);
         MM_HIP(hipGetLastError());
     }
+    // fp8 tower with the LayerNorm FOLDED into the QKV / FC1 GEMMs (round 5; hidden 1024 on the persistent fp8 kernel): the residual
+    // GEMMs' epilogue leaves the new bf16 rows as MXFP8 — raw — with their 256-column statistics, the QKV / FC1 epilogue applies
+    // (mean, rstd): 46 of the 47 LayerNorm launches of a ViT-L/14 encode disappear (tools/fp8_fold_sim.py: the same 1 - cos as
+    // LayerNorm-then-quantise). OFF by default (option fp8_ln_fold = 1 turns it on): measured inside the bs-128 encode the 1.03 ms
+    // of LayerNorm kernels (HBM-bound, 4.5 TB/s) come back as 1.3 ms of epilogue time in the GEMMs — +12 us per residual GEMM
+    // (half again as many bytes stored in the epilogue burst of 256 workgroups in step), +12 / +20 us per QKV / FC1 (two more packed
+    // operations per value and a workgroup barrier per tile), with the matrix pipes idle meanwhile: 9.19 k against 9.40 k images/s
+    // (tools/l14_fp8_ab.py, tools/l14_kernel_table.py).
+    bool fold8 = false;
+    if (fp8 && resid16 && !causal && d == 1024 && tw.layers >= 1 && tw.L[0].wqkv8f.p && tw.ctx8.p && attention_mx_ok(tw.T, tw.heads) &&
+        mmiss_option("fp8_outproj", 1) != 0 && mmiss_option("fp8_ln_fold", 0) != 0 && p8(MMISS_EPI8_BIAS_BF16, 3 * d, d) &&
+        p8(MMISS_EPI8_QGELU_MXFP8, tw.mlp, d) && p8(MMISS_EPI8_BIAS_RESID_BF16, d, d) && p8(MMISS_EPI8_BIAS_RESID_BF16, d, tw.mlp)) {
+        Gemm8Args t{};   // (the residual form must not end in a round of half tiles)
+        t.M = (int)round_up(M, 256); t.N = d; t.K = d; t.m_valid = M;
+        t.ragged = (t.M >= 512 && M > t.M - 256 && M <= t.M - 128 && mmiss_option("gemm_p256_ragged", 1) != 0) ? M - (t.M - 256) : 0;
+        t.q_out = tw.h8.as<uint8_t>(); t.q_scale = tw.hs.as<uint8_t>(); t.stats_out = tw.stats.as<float>(); t.ld_qs = mx_scale_row_bytes(d);
+        fold8 = gemm256p8_xt_ok(MMISS_EPI8_BIAS_RESID_BF16, 2, t);
+    }
+    if (fold8) {
+        MM_PROF("quant16_mxfp8_stats", st, 3.0 * M * d, 3.0 * M * d);
+        hipLaunchKernelGGL(quant16_mxfp8_stats_1024_kernel, dim3((M + 3) / 4), dim3(256), 0, st, tw.xb.as<uint16_t>(), tw.h8.as<uint8_t>(),
+                           tw.hs.as<uint8_t>(), tw.stats.as<float>(), M, mx_scale_row_bytes(d));
+        MM_HIP(hipGetLastError());
+    }
+    auto fold8_args = [&](Gemm8Args& g) {   // the consumer side: A = the raw rows as MXFP8, statistics, the bf16 rows for a ragged block
+        g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
+        g.ln_stats = tw.stats.as<float>(); g.x16 = tw.xb.as<uint16_t>(); g.ln_eps = eps;
+    };
+    auto mxq_args = [&](Gemm8Args& g) {     // the producer side
+        g.q_out = tw.h8.as<uint8_t>(); g.q_scale = tw.hs.as<uint8_t>(); g.ld_qs = mx_scale_row_bytes(d); g.stats_out = tw.stats.as<float>();
+    };
     for (int l = 0; l < tw.layers; ++l) {
         LayerW& L = tw.L[l];
         GemmEpi ep{};
         ep.out = tw.qkv.p; ep.bias = L.bqkv.as<float>(); ep.ldo = 3 * d; ep.m_valid = M;
-        if (fold) {
+        if (fold8) {
+            Gemm8Args g{};
+            fold8_args(g);
+            g.W = L.wqkv8f.as<uint8_t>(); g.wscale = L.sqkvf.as<float>(); g.bias = L.bqkv_f.as<float>(); g.c16 = L.cqkv16.as<uint16_t>();
+            g.out = tw.qkv.p; g.ldo = 3 * d; g.N = 3 * d; g.K = d; g.m_valid = M;
+            MM_TRY(gemm8_any(MMISS_EPI8_BIAS_BF16, bm8_qkv, g, 1));
+        } else if (fold) {
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = parts; ep.ln_eps = eps;
             if (p256(MMISS_EPI_LNFOLD_BF16, 3 * d)) {
@@ -481,7 +519,8 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             g.A = tw.ctx8.as<uint8_t>(); g.As = tw.ctxs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
             g.W = L.wo8.as<uint8_t>(); g.wscale = L.so.as<float>(); g.bias = L.bo.as<float>();
             g.out = tw.xb.p; g.ldo = d; g.N = d; g.K = d; g.m_valid = M;
-            MM_TRY(gemm8_any(MMISS_EPI8_BIAS_RESID_BF16, bm8_d, g));
+            if (fold8) mxq_args(g);
+            MM_TRY(gemm8_any(MMISS_EPI8_BIAS_RESID_BF16, bm8_d, g, fold8 ? 2 : 0));
         } else if (resid16) {  // the bf16 rows ARE the residual stream: read-modify-write in place, no f32 stream
             ep.out = tw.xb.p; ep.xb_out = nullptr;
             if (p160(d, d)) MM_TRY(launch_gemm160p(st, tw.ctx.p, L.wo.p, ep, padded(160), d, d));
@@ -503,20 +542,26 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
                 MM_TRY(launch_gemm_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, bm_mlp, tw.xb.p, L.w1_f.p, ep, padded(bm_mlp), tw.mlp, d));
             }
         } else if (fp8) {
-            // LN2 -> MXFP8, FC1 + QuickGELU -> MXFP8 (per row and 64 columns), FC2 + residual: `u` crosses HBM as 1 byte
-            MM_TRY(launch_layernorm_mxfp8(st, resid16 ? tw.xb.p : tw.x.p, resid16, L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h8.as<uint8_t>(),
-                                          tw.hs.as<uint8_t>(), M, d, eps));
+            // LN2 -> MXFP8 (fold8: folded into FC1), FC1 + QuickGELU -> MXFP8 (per row and 64 columns), FC2 + residual: `u` crosses HBM as 1 byte
             Gemm8Args g{};
-            g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
-            g.W = L.w1_8.as<uint8_t>(); g.wscale = L.s1.as<float>(); g.bias = L.b1.as<float>();
+            if (fold8) {
+                fold8_args(g);
+                g.W = L.w1_8f.as<uint8_t>(); g.wscale = L.s1f.as<float>(); g.bias = L.b1_f.as<float>(); g.c16 = L.c1_16.as<uint16_t>();
+            } else {
+                MM_TRY(launch_layernorm_mxfp8(st, resid16 ? tw.xb.p : tw.x.p, resid16, L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h8.as<uint8_t>(),
+                                              tw.hs.as<uint8_t>(), M, d, eps));
+                g.A = tw.h8.as<uint8_t>(); g.As = tw.hs.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(d);
+                g.W = L.w1_8.as<uint8_t>(); g.wscale = L.s1.as<float>(); g.bias = L.b1.as<float>();
+            }
             g.out = tw.u8.p; g.out_scale = tw.us.as<uint8_t>(); g.ld_os = mx_scale_row_bytes(tw.mlp);
             g.ldo = tw.mlp; g.N = tw.mlp; g.K = d; g.m_valid = M;
-            MM_TRY(gemm8_any(MMISS_EPI8_QGELU_MXFP8, bm8_mlp, g));
+            MM_TRY(gemm8_any(MMISS_EPI8_QGELU_MXFP8, bm8_mlp, g, fold8 ? 1 : 0));
             g = Gemm8Args{};
             g.A = tw.u8.as<uint8_t>(); g.As = tw.us.as<uint8_t>(); g.ld_as = mx_scale_row_bytes(tw.mlp);
             g.W = L.w2_8.as<uint8_t>(); g.wscale = L.s2.as<float>(); g.bias = L.b2.as<float>();
             g.out = resid16 ? tw.xb.p : tw.x.p; g.ldo = d; g.N = d; g.K = tw.mlp; g.m_valid = M;
-            MM_TRY(gemm8_any(resid16 ? MMISS_EPI8_BIAS_RESID_BF16 : MMISS_EPI8_BIAS_RESID_F32, bm8_d, g));
+            if (fold8) mxq_args(g);
+            MM_TRY(gemm8_any(resid16 ? MMISS_EPI8_BIAS_RESID_BF16 : MMISS_EPI8_BIAS_RESID_F32, bm8_d, g, fold8 ? 2 : 0));
             MM_TRY(tap(l + 1));
             continue;
         } else if (sfold) {
@@ -953,11 +998,24 @@ static int build_fp8_weights(mmiss_encoder* enc) {
             MM_HIP(hipGetLastError());
             return MMISS_OK;
         };
+        auto quant_fold = [&](DevBuf& wf, DevBuf& w8, DevBuf& sc, DevBuf& c16, int N, int K) -> int {
+            MM_TRY(w8.alloc((size_t)N * K));
+            MM_TRY(sc.alloc((size_t)N * 4));
+            MM_TRY(c16.alloc((size_t)N * 2));
+            hipLaunchKernelGGL(quantize_weights_fp8_csum_kernel, dim3((N + 3) / 4), dim3(256), 0, st, wf.as<uint16_t>(), w8.as<uint8_t>(),
+                               sc.as<float>(), c16.as<uint16_t>(), N, K);
+            MM_HIP(hipGetLastError());
+            return MMISS_OK;
+        };
         for (LayerW& L : tw->L) {
             MM_TRY(quant(L.wqkv, L.wqkv8, L.sqkv, 3 * d, d));
             MM_TRY(quant(L.w1, L.w1_8, L.s1, mlp, d));
             MM_TRY(quant(L.w2, L.w2_8, L.s2, d, mlp));
             MM_TRY(quant(L.wo, L.wo8, L.so, d, d));
+            if (d == 1024 && L.wqkv_f.p && L.w1_f.p) {   // the folded form (run_layers: fold8)
+                MM_TRY(quant_fold(L.wqkv_f, L.wqkv8f, L.sqkvf, L.cqkv16, 3 * d, d));
+                MM_TRY(quant_fold(L.w1_f, L.w1_8f, L.s1f, L.c1_16, mlp, d));
+            }
         }
         tw->fp8_ready = true;
     }
@@ -1504,6 +1562,43 @@ extern "C" int mmiss_dbg_gemm8(int device, void* hip_stream, int epi, int bm, co
         return launch_gemm256p8(reinterpret_cast<hipStream_t>(hip_stream), epi, g);
     }
     return launch_gemm8(reinterpret_cast<hipStream_t>(hip_stream), epi, bm, g);
+}
+
+extern "C" int mmiss_dbg_gemm8_xt(int device, void* hip_stream, int epi, int xt, const void* A8, const void* As, const void* W8,
+                                  const float* wscale, const float* bias, void* out, void* out_scale, int32_t M, int32_t N, int32_t K,
+                                  int32_t m_valid, const void* c16, const float* ln_stats, const void* x16, float ln_eps,
+                                  void* q_out, void* q_scale, float* stats_out) {
+    MM_TRY(mmiss_use_device(device));
+    Gemm8Args g{};
+    g.A = reinterpret_cast<const uint8_t*>(A8); g.As = reinterpret_cast<const uint8_t*>(As); g.ld_as = mx_scale_row_bytes(K);
+    g.W = reinterpret_cast<const uint8_t*>(W8); g.wscale = wscale; g.bias = bias; g.out = out;
+    g.out_scale = reinterpret_cast<uint8_t*>(out_scale); g.ld_os = mx_scale_row_bytes(N);
+    g.M = M; g.N = N; g.K = K; g.ldo = N; g.m_valid = m_valid > 0 && m_valid < M ? m_valid : M;
+    g.c16 = reinterpret_cast<const uint16_t*>(c16); g.ln_stats = ln_stats; g.x16 = reinterpret_cast<const uint16_t*>(x16); g.ln_eps = ln_eps;
+    g.q_out = reinterpret_cast<uint8_t*>(q_out); g.q_scale = reinterpret_cast<uint8_t*>(q_scale); g.ld_qs = mx_scale_row_bytes(N);
+    g.stats_out = stats_out;
+    return launch_gemm256p8(reinterpret_cast<hipStream_t>(hip_stream), epi, g, xt);
+}
+
+extern "C" int mmiss_dbg_quant16_mxfp8_stats(int device, void* hip_stream, const void* x_bf16, void* out8, void* out_scale,
+                                             float* stats, int32_t M, int32_t d) {
+    if (!x_bf16 || !out8 || !out_scale || !stats || M <= 0 || d != 1024) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_quant16_mxfp8_stats: bad argument (d must be 1024)");
+    MM_TRY(mmiss_use_device(device));
+    hipLaunchKernelGGL(quant16_mxfp8_stats_1024_kernel, dim3((M + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       reinterpret_cast<const uint16_t*>(x_bf16), reinterpret_cast<uint8_t*>(out8), reinterpret_cast<uint8_t*>(out_scale),
+                       stats, M, mx_scale_row_bytes(d));
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+
+extern "C" int mmiss_dbg_quantize_weights_fp8_csum(int device, void* hip_stream, const void* w_bf16, void* w8, float* scale, void* c16,
+                                                   int32_t N, int32_t K) {
+    if (!w_bf16 || !w8 || !scale || !c16 || N <= 0 || K <= 0 || (K % 4)) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_quantize_weights_fp8_csum: bad argument");
+    MM_TRY(mmiss_use_device(device));
+    hipLaunchKernelGGL(quantize_weights_fp8_csum_kernel, dim3((N + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       reinterpret_cast<const uint16_t*>(w_bf16), reinterpret_cast<uint8_t*>(w8), scale, reinterpret_cast<uint16_t*>(c16), N, K);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
 }
 
 extern "C" int mmiss_dbg_gemm8_time(int device, int epi, int bm, const void* A8, const void* As, const void* W8,

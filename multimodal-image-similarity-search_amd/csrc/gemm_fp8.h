@@ -49,6 +49,20 @@ struct Gemm8Args {
     // gemm256p8_kernel only: the last 256-row block holds `ragged` <= 128 valid rows (0: none). They are computed by a
     // register-streamed pass of all workgroups in front of the tile stream; the tiles then cover M - 256 rows.
     int ragged;
+    // gemm256p8_kernel<EPI, XT> only (gemm_fp8_p256.h). XT = 1, LayerNorm FOLDED into the BIAS_BF16 / QGELU_MXFP8 GEMMs (K = 1024):
+    // A8 / As are the RAW residual rows as MXFP8, W8 the gamma-folded weights, bias = b', c16 = f16 [N] row sums of the
+    // dequantised folded weights, ln_stats = [M][4][2] f32 (sum, sumsq) of every 256-column quarter of the bf16 residual row;
+    // y = rstd (acc sw - mean c) + b'. x16 = those bf16 rows [M, K] (the ragged pass takes its rows' statistics from them).
+    const uint16_t* c16;
+    const float* ln_stats;
+    const uint16_t* x16;
+    float ln_eps;
+    // XT = 2, BIAS_RESID_BF16 that ALSO leaves the new bf16 rows as MXFP8 (q_out e4m3 [M, N], q_scale E8M0 [M, ld_qs] permuted)
+    // and their statistics stats_out [M][N/256][2] (tile rows only: a ragged block's rows get theirs in the consumer)
+    uint8_t* q_out;
+    uint8_t* q_scale;
+    float* stats_out;
+    int ld_qs;
 };
 
 // bytes per row of a permuted scale array for K columns
@@ -380,6 +394,93 @@ __global__ __launch_bounds__(256) void quantize_weights_fp8_kernel(const uint16_
         *reinterpret_cast<uint32_t*>(W8 + (size_t)n * K + k) = pack_fp8x4(a, b, c, d);
     }
     if (lane == 0) scale[n] = sc;
+}
+
+// The same for weights that carry a folded LayerNorm gamma (W' = bf16(W gamma), fold_ln_weights_kernel): e4m3 codes + per-channel
+// scale + c16[n] = f16(sum_k of the DEQUANTISED codes) — the row sum the folded fp8 GEMM's epilogue multiplies the row mean by
+// (gemm_fp8_p256.h, XT = 1): of the quantised weights, because those are what the matrix cores multiply.
+__global__ __launch_bounds__(256) void quantize_weights_fp8_csum_kernel(const uint16_t* __restrict__ Wb, uint8_t* __restrict__ W8,
+                                                                        float* __restrict__ scale, uint16_t* __restrict__ c16, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint16_t* w = Wb + (size_t)n * K;
+    float amax = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(w + k);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16_bits_to_f32(v[0] & 0xffff)), fabsf(bf16_bits_to_f32(v[0] >> 16))),
+                                 fmaxf(fabsf(bf16_bits_to_f32(v[1] & 0xffff)), fabsf(bf16_bits_to_f32(v[1] >> 16)))));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    float csum = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(w + k);
+        const float a = fminf(fmaxf(bf16_bits_to_f32(v[0] & 0xffff) * inv, -448.f), 448.f);
+        const float b = fminf(fmaxf(bf16_bits_to_f32(v[0] >> 16) * inv, -448.f), 448.f);
+        const float c = fminf(fmaxf(bf16_bits_to_f32(v[1] & 0xffff) * inv, -448.f), 448.f);
+        const float d = fminf(fmaxf(bf16_bits_to_f32(v[1] >> 16) * inv, -448.f), 448.f);
+        const uint32_t q = pack_fp8x4(a, b, c, d);
+        *reinterpret_cast<uint32_t*>(W8 + (size_t)n * K + k) = q;
+        // the codes' values, exactly (e4m3 -> f32): sums of at most a few thousand multiples of 2^-9 below 2^9 are exact in f32
+        const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)q, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)q, true);
+        csum += (lo[0] + lo[1]) + (hi[0] + hi[1]);
+    }
+    csum = wave_sum(csum);
+    if (lane == 0) {
+        scale[n] = sc;
+        const _Float16 h = (_Float16)(csum * sc);
+        c16[n] = __builtin_bit_cast(uint16_t, h);
+    }
+}
+
+// Entry of the folded fp8 mode (hidden 1024): the bf16 residual rows as MXFP8 — RAW, no LayerNorm — and (sum, sumsq) of each
+// 256-column quarter of every row, [M][4][2] f32: what the residual GEMMs' XT = 2 epilogue leaves behind from then on.
+// One wave per row, lane l holds columns 16 l .. + 15 (two lanes = one 32-column block, 16 lanes = one quarter).
+__global__ __launch_bounds__(256) void quant16_mxfp8_stats_1024_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ out,
+                                                                       uint8_t* __restrict__ out_scale, float* __restrict__ stats, int M,
+                                                                       int ld_os) {
+    constexpr int D = 1024;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int c = lane * 16;
+    const u32x4 r0 = *reinterpret_cast<const u32x4*>(x + (size_t)r * D + c), r1 = *reinterpret_cast<const u32x4*>(x + (size_t)r * D + c + 8);
+    float v[16];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        v[2 * w] = __uint_as_float(r0[w] << 16);
+        v[2 * w + 1] = __uint_as_float(r0[w] & 0xFFFF0000u);
+        v[8 + 2 * w] = __uint_as_float(r1[w] << 16);
+        v[8 + 2 * w + 1] = __uint_as_float(r1[w] & 0xFFFF0000u);
+    }
+    float s1 = 0.f, s2 = 0.f, amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        s1 += v[e];
+        s2 += v[e] * v[e];
+        amax = fmaxf(amax, fabsf(v[e]));
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {   // the 16 lanes of a quarter, fixed order
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    int e8;
+    float inv;
+    mx_scale_of(amax, e8, inv);
+    u32x4 pk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pk[i] = pack_fp8x4(v[4 * i] * inv, v[4 * i + 1] * inv, v[4 * i + 2] * inv, v[4 * i + 3] * inv);
+    *reinterpret_cast<u32x4*>(out + (size_t)r * D + c) = pk;
+    if ((lane & 1) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
+    if ((lane & 15) == 0) {
+        float* so = stats + ((size_t)r * 4 + (lane >> 4)) * 2;
+        so[0] = s1;
+        so[1] = s2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,8 +40,11 @@
 #define Q256_BC (8 * G256_SLOT)        // 2 x 2 KB: bias [256] f32 + wscale [256] f32 of the current / next tile
 #define Q256_TILES (Q256_BC + 4096)    // this workgroup's tile list: 64 x packed (bm, bn, half)
 #define Q256_RING (Q256_TILES + 256)   // 2 x 4 KB: scale dwords [parity][A slot mq][slot row 128][k-block 4]
-#define Q256_PATCH (Q256_RING + 8192)  // 8 waves x 2 KB: the epilogue's transposes
+#define Q256_PATCH (Q256_RING + 8192)  // 8 waves x 2 KB: the epilogue's transposes (XT = 1: a wave's 1 KB of raw row statistics lands here during the K stream)
 #define Q256_LDS (Q256_PATCH + 16384)
+#define Q256_C16 Q256_LDS              // XT = 1: 2 x 512 B: c [256] f16 of the current / next tile
+#define Q256_TABLE (Q256_C16 + 1024)   // XT = 1: 256 x (mean, rstd) of the tile's rows
+#define Q256_LDS_FOLD (Q256_TABLE + 2048)
 
 // max over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four lane groups that hold one row's columns) by two swaps in the vector unit
 // (v_permlane32_swap, v_permlane16_swap): __shfl_xor's ds_bpermute takes its address from the lane id, a register the
@@ -55,11 +58,36 @@ __device__ __forceinline__ float q256_max_over_lane_groups(float v) {
     return fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
 }
 
-template <int EPI>
+// XT: 0 plain; 1 = LayerNorm folded in (BIAS_BF16 / QGELU_MXFP8; Gemm8Args); 2 = BIAS_RESID_BF16 + MXFP8 copy + row statistics
+__device__ __forceinline__ float q256_sum_over_lane_groups(float v) {   // sum over lanes l, l ^ 16, l ^ 32, l ^ 48: (l + l^32) + (l^16 + l^48)
+    uint32_t u = __float_as_uint(v);
+    auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+    u = __float_as_uint(v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float q256_dpp(float v) {   // the value of the lane CTRL names: 0xB1 / 0x4E = lane ^ 1 / ^ 2 (quad permutes), 0x141 = 7 - lane within 8
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ f32x4 q256_halves_to_f32x4(u32x2 h) {   // four f16 -> f32
+    // (scalar bit casts of the two words: a bit_cast of the vector's ELEMENTS to a two-half vector came out of hipcc as the first
+    // word twice)
+    const uint32_t w0 = h[0], w1 = h[1];
+    return f32x4{(float)__builtin_bit_cast(_Float16, (uint16_t)(w0 & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(w0 >> 16)),
+                 (float)__builtin_bit_cast(_Float16, (uint16_t)(w1 & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(w1 >> 16))};
+}
+
+template <int EPI, int XT = 0>
 __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(EPI == MMISS_EPI8_BIAS_BF16 || EPI == MMISS_EPI8_QGELU_MXFP8 || EPI == MMISS_EPI8_BIAS_RESID_BF16, "epilogue");
-    constexpr int EX = 16 + 1;  // vector-memory operations of a wave between two tiles' K streams: 16 stores + the bias / wscale piece
+    static_assert(XT == 0 || (XT == 1 && EPI != MMISS_EPI8_BIAS_RESID_BF16) || (XT == 2 && EPI == MMISS_EPI8_BIAS_RESID_BF16), "extension");
+    constexpr bool FOLD = XT == 1, MXQ = XT == 2;
+    // vector-memory operations of a wave between two tiles' K streams: the epilogue's stores (16; MXQ: 5 x 8 + the statistics) + the
+    // pieces of stage_x (bias / wscale; FOLD: + c + the raw statistics)
+    constexpr int EX = (MXQ ? 41 : 16) + (FOLD ? 3 : 1);
     // An (unused) value of the accumulator register class makes the compiler select the MFMAs in their AGPR form: the 128
     // accumulators live in a[0:127], the 128 arch VGPRs are left to the 8-register operand tuples of the K = 128 MFMA, the
     // addresses and the epilogue. With everything in one file of 256 registers the allocator could not keep sixteen 8-tuples
@@ -133,13 +161,40 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                 const bool epi_wave = c0 < NC;
                 const bool live = m < g.m_valid;
                 f32x4 wsv[NE], bv[NE];
+                [[maybe_unused]] f32x4 cv[NE];
                 u32x2 oldv[NE];
+                if constexpr (FOLD) {
+                    // (mean, rstd) of the unit's 16 rows from the bf16 residual rows themselves (the producing GEMM's statistics
+                    // cover tile rows only): wave w sums rows 2 w and 2 w + 1, 16 values per lane, and leaves them behind `red`
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int row = row0 + rg * 16 + 2 * wave + rr;
+                        const u32x4 h0 = *reinterpret_cast<const u32x4*>(g.x16 + (size_t)row * K + lane * 16);
+                        const u32x4 h1 = *reinterpret_cast<const u32x4*>(g.x16 + (size_t)row * K + lane * 16 + 8);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = __uint_as_float(h0[e] << 16), b = __uint_as_float(h0[e] & 0xFFFF0000u);
+                            const float c = __uint_as_float(h1[e] << 16), d = __uint_as_float(h1[e] & 0xFFFF0000u);
+                            s1 += (a + b) + (c + d);
+                            s2 += (a * a + b * b) + (c * c + d * d);
+                        }
+                        s1 = wave_sum(s1);
+                        s2 = wave_sum(s2);
+                        const float mean = s1 * (1.0f / 1024.0f);
+                        const float var = fmaxf(s2 * (1.0f / 1024.0f) - mean * mean, 0.f);
+                        if (lane == 0)
+                            *reinterpret_cast<u32x2*>(smem + 65536 + (2 * wave + rr) * 8) =
+                                u32x2{__float_as_uint(mean), __float_as_uint(1.0f / sqrtf(var + g.ln_eps))};
+                    }
+                }
                 if (epi_wave) {
 #pragma unroll
                     for (int c = 0; c < NE; ++c) {
                         const int n = n0 + (c0 + c) * 16 + 4 * fg;
                         wsv[c] = *reinterpret_cast<const f32x4*>(g.wscale + n);
                         bv[c] = *reinterpret_cast<const f32x4*>(g.bias + n);
+                        if constexpr (FOLD) cv[c] = q256_halves_to_f32x4(*reinterpret_cast<const u32x2*>(g.c16 + n));
                         if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16)
                             oldv[c] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(g.out) + (size_t)(live ? m : M - 1) * g.ldo + n);
                     }
@@ -154,7 +209,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                         f32x4 sum = red[(c0 + c) * 64 + lane];
 #pragma unroll
                         for (int w = 1; w < 8; ++w) sum = sum + red[(w * 8 + c0 + c) * 64 + lane];
-                        y[c] = sum * wsv[c] + bv[c];
+                        if constexpr (FOLD) {
+                            const float mean = *reinterpret_cast<const float*>(smem + 65536 + fr * 8);
+                            const float rstd = *reinterpret_cast<const float*>(smem + 65536 + fr * 8 + 4);
+                            y[c] = (sum * wsv[c] - mean * cv[c]) * rstd + bv[c];
+                        } else {
+                            y[c] = sum * wsv[c] + bv[c];
+                        }
                         if constexpr (EPI == MMISS_EPI8_QGELU_MXFP8) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -187,6 +248,32 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                             pk[0] = pack_bf16x2(y[c][0], y[c][1]);
                             pk[1] = pack_bf16x2(y[c][2], y[c][3]);
                             *reinterpret_cast<u32x2*>(orow + c * 16) = pk;
+                            if constexpr (MXQ)
+                                y[c] = f32x4{__uint_as_float(pk[0] << 16), __uint_as_float(pk[0] & 0xFFFF0000u), __uint_as_float(pk[1] << 16),
+                                             __uint_as_float(pk[1] & 0xFFFF0000u)};
+                        }
+                    }
+                    if constexpr (MXQ) {
+                        // the MXFP8 copy of the new bf16 rows: NE / 2 whole 32-column blocks per epilogue wave (every lane takes part
+                        // in the lane-group maxima; only live rows store). The rows' statistics are the consumer's business.
+#pragma unroll
+                        for (int b = 0; b < NE / 2; ++b) {
+                            float amax = 0.f;
+#pragma unroll
+                            for (int c = 2 * b; c < 2 * b + 2; ++c)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(y[c][r]));
+                            amax = q256_max_over_lane_groups(amax);
+                            int e8;
+                            float inv;
+                            mx_scale_of(amax, e8, inv);
+                            if (live) {
+#pragma unroll
+                                for (int c = 2 * b; c < 2 * b + 2; ++c)
+                                    *reinterpret_cast<uint32_t*>(g.q_out + (size_t)m * N + nb + c * 16 + 4 * fg) =
+                                        pack_fp8x4(y[c][0] * inv, y[c][1] * inv, y[c][2] * inv, y[c][3] * inv);
+                                if (fg == 0) g.q_scale[(size_t)m * g.ld_qs + mx_scale_offset((nb >> 5) + b)] = (uint8_t)e8;
+                            }
                         }
                     }
                 }
@@ -286,9 +373,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     }
     // bias / weight scales of tile (., bn): one 4-byte piece per wave
     const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wave >= 4 ? g.wscale : g.bias), 0, 0x7fffffff, 0x00020000);
-    auto stage_x = [&](int bn, int par) {
-        const int l4 = lane_now() * 4;   // (recomputed: no 64-bit lane address kept)
-        Q256_BLDS4(srdX, l4, (bn * 256 + (wave & 3) * 64) * 4, smem + Q256_BC + par * 2048 + wave * 256);
+    auto stage_x = [&](int bm, int bn, int par) {
+        const int l = lane_now();        // (recomputed: no 64-bit lane address kept)
+        Q256_BLDS4(srdX, l * 4, (bn * 256 + (wave & 3) * 64) * 4, smem + Q256_BC + par * 2048 + wave * 256);
+        if constexpr (FOLD) {
+            // c [256] f16 = 512 B: two 4-byte pieces (waves of equal parity bring the same bytes); the tile rows' raw statistics:
+            // 256 rows x 32 B, rows 32 wave .. + 31 into this wave's OWN patch (free until its next epilogue)
+            const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(g.c16), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t srdT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.ln_stats), 0, 0x7fffffff, 0x00020000);
+            Q256_BLDS4(srdC, l * 4, (bn * 256 + (wave & 1) * 128) * 2, smem + Q256_C16 + par * 512 + (wave & 1) * 256);
+            Q256_BLDS(srdT, l * 16, (bm * 256 + wave * 32) * 32, smem + Q256_PATCH + wave * 2048);
+        }
     };
 
     // ---- fragment reads: one base per operand and 64-k half + immediates (slot, 16-row sub-tile)
@@ -429,7 +524,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     // A m1 slot (staged by phase 0 of K-tile 0)
     Q256_SCALE_PIECE();
     Q256_SCALE_PIECE();
-    stage_x(cbn, 0);
+    stage_x(cbm, cbn, 0);
     {
         char* d0 = smem + stage_dst;
         Q256_BLDS(srdA, a_vo, oA1, d0 + Q256_SLOT(0, 0)); Q256_BLDS(srdA, a_vo, oA1 + row8, d0 + Q256_SLOT(0, 0) + 1024);
@@ -466,14 +561,35 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
         const int m_base = cbm * 256 + wm * 128 + hrow;
         const int n_base = cbn * 256 + wn * 64;
         const __amdgpu_buffer_rsrc_t srdO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, 0x7fffffff, 0x00020000);
+        // FOLD: (mean, rstd) of the tile's 256 rows. This wave's patch holds the raw (sum, sumsq) quarters of rows 32 wave .. + 31
+        // (stage_x, a whole K stream ago); lanes 0..31 finish one row each into the table; a barrier hands the table to everybody
+        // (the lower wave half was aligned with the upper one in front of the epilogue: all eight waves are here).
+        const float* tab = reinterpret_cast<const float*>(smem + Q256_TABLE) + (wm * 128 + hrow + fr) * 2;   // + j * 32
+        const char* cc = smem + Q256_C16 + par * 512 + (wn * 64 + 4 * fg) * 2;                                // + i * 32
+#define Q256_C(i) q256_halves_to_f32x4(*reinterpret_cast<const u32x2*>(cc + (i) * 32))
+        [[maybe_unused]] f32x4 cf[4];   // FOLD: c of this lane's 16 columns, converted once (per (i, j) it was 128 conversions + 32 LDS reads a lane)
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cf[i] = Q256_C(i);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(patch + (lane_e & 31) * 32);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(patch + (lane_e & 31) * 32 + 16);
+            const float s1 = (q0[0] + q0[2]) + (q1[0] + q1[2]), s2 = (q0[1] + q0[3]) + (q1[1] + q1[3]);
+            const float mean = s1 * (1.0f / 1024.0f);
+            const float var = fmaxf(s2 * (1.0f / 1024.0f) - mean * mean, 0.f);
+            if (lane_e < 32)
+                *reinterpret_cast<u32x2*>(smem + Q256_TABLE + (wave * 32 + lane_e) * 8) =
+                    u32x2{__float_as_uint(mean), __float_as_uint(1.0f / sqrtf(var + g.ln_eps))};
+            Q256_BARRIER();
+        }
         if constexpr (EPI == MMISS_EPI8_BIAS_BF16 || EPI == MMISS_EPI8_BIAS_RESID_BF16) {
             // 16 rows x 64 bf16 columns through the patch: 8-byte slot s of row r at slot s ^ 2 (r & 7); whole 128-byte rows per store
             const int wr_off = fr * 128, wr_sw = 2 * (fr & 7);
+            [[maybe_unused]] const __amdgpu_buffer_rsrc_t srdQO = __builtin_amdgcn_make_buffer_rsrc(MXQ ? g.q_out : nullptr, 0, 0x7fffffff, 0x00020000);
+            [[maybe_unused]] const __amdgpu_buffer_rsrc_t srdQS = __builtin_amdgcn_make_buffer_rsrc(MXQ ? g.q_scale : nullptr, 0, 0x7fffffff, 0x00020000);
             // the residual rows, four 16-row sub-tiles (64 rows x 128 bytes per wave, 32 registers) fetched at a time
             u32x4 old[EPI == MMISS_EPI8_BIAS_RESID_BF16 ? 4 : 1][2];
 #pragma unroll
             for (int j = 0; j < JN; ++j) {
-                f32x4 res[4];
                 if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16) {
                     if ((j & 3) == 0) {
 #pragma unroll
@@ -494,18 +610,21 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const u32x2 o2_ = *reinterpret_cast<const u32x2*>(patch + wr_off + (((i * 4 + fg) ^ wr_sw) << 3));
-                        res[i] = f32x4{__uint_as_float(o2_[0] << 16), __uint_as_float(o2_[0] & 0xFFFF0000u),
-                                       __uint_as_float(o2_[1] << 16), __uint_as_float(o2_[1] & 0xFFFF0000u)};
-                    }
-                    __builtin_amdgcn_wave_barrier();  // every lane has read before the patch is rewritten
+                    // (a lane reads the old values of column block i from the very 8 bytes it then overwrites with the new ones: no
+                    // second barrier, and one block's old values in registers at a time)
                 }
+                float rm_j = 0.f, rstd_j = 1.f;   // FOLD: y = acc (sw rstd) + (c (-mean rstd) + b')
+                if constexpr (FOLD) { rstd_j = tab[j * 32 + 1]; rm_j = -tab[j * 32] * rstd_j; }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    f32x4 y = acc[i][j] * Q256_SW(i) + Q256_BIAS(i);
-                    if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16) y = res[i] + y;
+                    f32x4 y;
+                    if constexpr (FOLD) y = acc[i][j] * (Q256_SW(i) * rstd_j) + (cf[i] * rm_j + Q256_BIAS(i));
+                    else y = acc[i][j] * Q256_SW(i) + Q256_BIAS(i);
+                    if constexpr (EPI == MMISS_EPI8_BIAS_RESID_BF16) {
+                        const u32x2 o2_ = *reinterpret_cast<const u32x2*>(patch + wr_off + (((i * 4 + fg) ^ wr_sw) << 3));
+                        y = f32x4{__uint_as_float(o2_[0] << 16), __uint_as_float(o2_[0] & 0xFFFF0000u), __uint_as_float(o2_[1] << 16),
+                                  __uint_as_float(o2_[1] & 0xFFFF0000u)} + y;
+                    }
                     u32x2 pk;
                     pk[0] = pack_bf16x2(y[0], y[1]);
                     pk[1] = pack_bf16x2(y[2], y[3]);
@@ -515,16 +634,89 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                [[maybe_unused]] float rs1[2], rs2[2];
+                [[maybe_unused]] int re8[2];
 #pragma unroll
                 for (int rh = 0; rh < 2; ++rh) {
                     const int row = rh * 8 + rrow;
                     const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * 128 + (((2 * rchunk) ^ (2 * (row & 7))) << 3));
                     const int m = m_base + j * 16 + row;
-                    const int vo = ((m < g.m_valid ? m : dump_row) * g.ldo + n_base + rchunk * 8) * 2;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, srdO, vo, 0, 0);
+                    const int mrow = m < g.m_valid ? m : dump_row;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, srdO, (mrow * g.ldo + n_base + rchunk * 8) * 2, 0, 0);
+                    if constexpr (MXQ) {
+                        // the MXFP8 copy and the statistics, in the ROW layout the bf16 rows leave in: this lane holds 8 consecutive
+                        // columns of the row, 4 neighbouring lanes a 32-column block, 8 a row's 64 columns — two quad permutes for
+                        // the block maximum, those and a half-row mirror for the sums (in the accumulator layout it was 200
+                        // vector instructions and 13 LDS operations per sub-tile)
+                        float x[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[e] << 16); x[2 * e + 1] = __uint_as_float(v[e] & 0xFFFF0000u); }
+                        float s1 = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                        float s2 = ((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3])) + ((x[4] * x[4] + x[5] * x[5]) + (x[6] * x[6] + x[7] * x[7]));
+                        float am = fmaxf(fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))),
+                                         fmaxf(fmaxf(fabsf(x[4]), fabsf(x[5])), fmaxf(fabsf(x[6]), fabsf(x[7]))));
+                        am = fmaxf(am, q256_dpp<0xB1>(am));
+                        am = fmaxf(am, q256_dpp<0x4E>(am));
+                        s1 += q256_dpp<0xB1>(s1); s2 += q256_dpp<0xB1>(s2);
+                        s1 += q256_dpp<0x4E>(s1); s2 += q256_dpp<0x4E>(s2);
+                        s1 += q256_dpp<0x141>(s1); s2 += q256_dpp<0x141>(s2);
+                        float inv;
+                        mx_scale_of(am, re8[rh], inv);
+                        u32x2 q;
+                        q[0] = pack_fp8x4(x[0] * inv, x[1] * inv, x[2] * inv, x[3] * inv);
+                        q[1] = pack_fp8x4(x[4] * inv, x[5] * inv, x[6] * inv, x[7] * inv);
+                        __builtin_amdgcn_raw_buffer_store_b64(q, srdQO, mrow * g.N + n_base + rchunk * 8, 0, 0);
+                        rs1[rh] = s1;
+                        rs2[rh] = s2;
+                    }
+                }
+                if constexpr (MXQ) {
+                    // the scale bytes of the sub-tile's 16 rows x 2 blocks: lanes with rchunk 0 / 4 hold those of row rrow, 1 / 5 those of
+                    // row 8 + rrow (every lane runs the ONE store; 32 are active)
+                    const int row = ((rchunk & 1) ? 8 : 0) + rrow;
+                    const int m = m_base + j * 16 + row;
+                    const int vo = (m < g.m_valid ? m : dump_row) * g.ld_qs + mx_scale_offset((n_base >> 5) + (rchunk >> 2));
+                    if ((rchunk & 2) == 0) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)((rchunk & 1) ? re8[1] : re8[0]), srdQS, vo, 0, 0);
+                    // the rows' sums over the wave's 64 columns, parked in four of the sub-tile's (consumed) accumulator registers until
+                    // the end of the epilogue: arch VGPRs held across the sub-tiles were spilled ones
+                    acc[0][j][0] = rs1[0]; acc[0][j][1] = rs2[0]; acc[0][j][2] = rs1[1]; acc[0][j][3] = rs2[1];
                 }
                 __builtin_amdgcn_wave_barrier();  // the patch is rewritten by the next j
                 __builtin_amdgcn_sched_barrier(0);   // (one sub-tile's accumulators in VGPRs at a time)
+            }
+            if constexpr (MXQ) {
+                // row statistics of the tile: every wave leaves its rows' 64-column sums in its own patch (row j 16 + fr of its
+                // half at 8 bytes), a barrier, then wave w adds the four column blocks of tile rows 32 w .. + 31 in block order
+                // and stores them: stats_out[m][bn] — ONE store per wave.
+                {
+                    float k[4] = {0.f, 0.f, 0.f, 0.f};   // lane (rrow, rchunk) writes sub-tile j = rchunk's rows rrow and 8 + rrow
+#pragma unroll
+                    for (int q = 0; q < JN; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            k[e] = rchunk == q ? acc[0][q][e] : k[e];
+                            acc[0][q][e] = 0.f;
+                        }
+                    if (rchunk < JN) {
+                        *reinterpret_cast<u32x2*>(patch + (rchunk * 16 + rrow) * 8) = u32x2{__float_as_uint(k[0]), __float_as_uint(k[1])};
+                        *reinterpret_cast<u32x2*>(patch + (rchunk * 16 + 8 + rrow) * 8) = u32x2{__float_as_uint(k[2]), __float_as_uint(k[3])};
+                    }
+                }
+                Q256_BARRIER();
+                const int R = wave * 32 + (lane_e & 31);          // tile row
+                const char* src = smem + Q256_PATCH + (R >> 7) * 4 * 2048 + (R & 127) * 8;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const u32x2 v = *reinterpret_cast<const u32x2*>(src + b * 2048);
+                    t1 += __uint_as_float(v[0]);
+                    t2 += __uint_as_float(v[1]);
+                }
+                const int m = cbm * 256 + R;
+                const __amdgpu_buffer_rsrc_t srdST = __builtin_amdgcn_make_buffer_rsrc(g.stats_out, 0, 0x7fffffff, 0x00020000);
+                if (lane_e < 32)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(t1), __float_as_uint(t2)}, srdST,
+                                                          (((m < g.m_valid ? m : dump_row) * nbn + cbn) * 2) * 4, 0, 0);
             }
         } else {
             // QuickGELU -> MXFP8: ONE scale per row and the wave's 64 columns (= k-blocks n/32 and n/32 + 1 of the next GEMM, the
@@ -537,7 +729,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                 float amax = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    y[i] = acc[i][j] * Q256_SW(i) + Q256_BIAS(i);
+                    if constexpr (FOLD) {
+                        const float rstd_j = tab[j * 32 + 1], rm_j = -tab[j * 32] * rstd_j;
+                        y[i] = acc[i][j] * (Q256_SW(i) * rstd_j) + (cf[i] * rm_j + Q256_BIAS(i));
+                    } else {
+                        y[i] = acc[i][j] * Q256_SW(i) + Q256_BIAS(i);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         y[i][r] = quick_gelu(y[i][r]);
@@ -593,7 +790,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
         lane_consts();
         if (ti + 1 < mine) {
             tile_of(ti + 1, cbm, cbn, chalf);
-            stage_x(cbn, (ti + 1) & 1);
+            stage_x(cbm, cbn, (ti + 1) & 1);
             if (wm == 1) Q256_BARRIER();
         }
     }
@@ -619,6 +816,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
 #undef Q256_PIN
 #undef Q256_BIAS
 #undef Q256_SW
+#undef Q256_C
 #undef Q256_BLDS
 #undef Q256_BLDS4
 #undef Q256_STAGE
@@ -640,18 +838,33 @@ static inline bool gemm256p8_ok(int epi, int M, int N, int K) {
     return epi == MMISS_EPI8_BIAS_BF16 || epi == MMISS_EPI8_QGELU_MXFP8 || epi == MMISS_EPI8_BIAS_RESID_BF16;
 }
 
-template <int EPI>
+template <int EPI, int XT>
 static int launch_gemm256p8_inst(hipStream_t st, const Gemm8Args& g) {
     const int T = (g.M / 256 - (g.ragged > 0 ? 1 : 0)) * (g.N / 256);
     const int grid = T >= 256 ? 256 : T;
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p8_kernel<EPI>), Q256_LDS));
-    hipLaunchKernelGGL((gemm256p8_kernel<EPI>), dim3(grid), dim3(512), Q256_LDS, st, g);
+    constexpr int LDS = XT == 1 ? Q256_LDS_FOLD : Q256_LDS;
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p8_kernel<EPI, XT>), LDS));
+    hipLaunchKernelGGL((gemm256p8_kernel<EPI, XT>), dim3(grid), dim3(512), LDS, st, g);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }
 
+// the extensions of round 5 (Gemm8Args): xt = 1 LayerNorm folded into BIAS_BF16 / QGELU_MXFP8 (K = 1024), xt = 2 BIAS_RESID_BF16 that
+// also leaves the new rows as MXFP8 with their statistics (N = 1024; no half tiles: the tile count must not end in a short round)
+static inline bool gemm256p8_xt_ok(int epi, int xt, const Gemm8Args& g) {
+    if (xt == 0) return true;
+    if (xt == 1)
+        return (epi == MMISS_EPI8_BIAS_BF16 || epi == MMISS_EPI8_QGELU_MXFP8) && g.K == 1024 && g.c16 && g.ln_stats && g.x16;
+    if (xt != 2 || epi != MMISS_EPI8_BIAS_RESID_BF16 || g.N != 1024 || !g.q_out || !g.q_scale || !g.stats_out ||
+        g.ld_qs < mx_scale_row_bytes(g.N) || (int64_t)g.M * g.ld_qs >= (1LL << 31))
+        return false;
+    const int T = (g.M / 256 - (g.ragged > 0 ? 1 : 0)) * (g.N / 256), G = T >= 256 ? 256 : T;
+    const int rem = T % G;
+    return !(T / G >= 1 && rem > 0 && 2 * rem <= G);
+}
+
 // g.M = rows padded to 256 (A8, As, out and out_scale must hold g.M rows); rows >= g.m_valid are computed and land in row M - 1.
-static int launch_gemm256p8(hipStream_t st, int epi, Gemm8Args g) {
+static int launch_gemm256p8(hipStream_t st, int epi, Gemm8Args g, int xt = 0) {
     if (!gemm256p8_ok(epi, g.M, g.N, g.K) || !g.A || !g.As || !g.W || !g.wscale || !g.bias || !g.out || g.ld_as < mx_scale_row_bytes(g.K) ||
         (int64_t)g.M * g.ld_as >= (1LL << 31))
         MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256p8: epi=%d M=%d N=%d K=%d ld_as=%d", epi, g.M, g.N, g.K, g.ld_as);
@@ -662,11 +875,18 @@ static int launch_gemm256p8(hipStream_t st, int epi, Gemm8Args g) {
     g.ragged = 0;
     if (g.M >= 512 && g.m_valid > g.M - 256 && g.m_valid <= g.M - 128 && mmiss_option("gemm_p256_ragged", 1) != 0)
         g.ragged = g.m_valid - (g.M - 256);
+    if (!gemm256p8_xt_ok(epi, xt, g)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256p8: extension %d of epilogue %d at M=%d N=%d K=%d", xt, epi, g.M, g.N, g.K);
     static const char* names[] = {"gemm_fp8_bias_p256", "gemm_fp8_qgelu_mx_p256", "", "gemm_fp8_bias_resid16_p256"};
+    static const char* names_x[] = {"gemm_fp8_lnfold_bias_p256", "gemm_fp8_lnfold_qgelu_mx_p256", "", "gemm_fp8_bias_resid16_mxq_p256"};
     const int mv = g.m_valid < g.M ? g.m_valid : g.M;
-    const double out_b = epi == MMISS_EPI8_BIAS_BF16 ? 2.0 : (epi == MMISS_EPI8_QGELU_MXFP8 ? 1.0 : 4.0);
-    MM_PROF(names[epi], st, 2.0 * mv * (double)g.N * g.K, (double)mv * g.K + (double)g.N * g.K + out_b * mv * g.N);
-    if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_BF16>(st, g);
-    if (epi == MMISS_EPI8_QGELU_MXFP8) return launch_gemm256p8_inst<MMISS_EPI8_QGELU_MXFP8>(st, g);
-    return launch_gemm256p8_inst<MMISS_EPI8_BIAS_RESID_BF16>(st, g);
+    const double out_b = epi == MMISS_EPI8_BIAS_BF16 ? 2.0 : (epi == MMISS_EPI8_QGELU_MXFP8 ? 1.0 : (xt == 2 ? 5.0 : 4.0));
+    MM_PROF(xt ? names_x[epi] : names[epi], st, 2.0 * mv * (double)g.N * g.K, (double)mv * g.K + (double)g.N * g.K + out_b * mv * g.N);
+    if (xt == 1) {
+        if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_BF16, 1>(st, g);
+        return launch_gemm256p8_inst<MMISS_EPI8_QGELU_MXFP8, 1>(st, g);
+    }
+    if (xt == 2) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_RESID_BF16, 2>(st, g);
+    if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_BF16, 0>(st, g);
+    if (epi == MMISS_EPI8_QGELU_MXFP8) return launch_gemm256p8_inst<MMISS_EPI8_QGELU_MXFP8, 0>(st, g);
+    return launch_gemm256p8_inst<MMISS_EPI8_BIAS_RESID_BF16, 0>(st, g);
 }

@@ -15,8 +15,8 @@ def t(n=8):
     for _ in range(n): enc.encode_image(x, out=o)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 for rnd in range(3):
-    for name, opts in (("base", {}), ("ln rw8", {"ln_mxfp8_wide": 3}), ("ln packed scales", {"ln_mxfp8_wide": 5}), ("attention_long", {"attention_stream": 0}), ("ragged off", {"gemm_p256_ragged": 0}), ("p256 fp8 off", {"gemm_p256_fp8": 0})):
+    for name, opts in (("base", {}), ("attention_long", {"attention_stream": 0}), ("LayerNorm folded (fp8_ln_fold)", {"fp8_ln_fold": 1}), ("ragged off", {"gemm_p256_ragged": 0}), ("p256 fp8 off", {"gemm_p256_fp8": 0})):
         for k, v in opts.items(): _lib.set_option(k, v)
         dt = t()
-        for k in opts: _lib.set_option(k, {"ln_mxfp8_wide": 1, "gemm_p256_ragged": 1, "gemm_p256_fp8": 1, "attention_stream": 1}[k])
+        for k in opts: _lib.set_option(k, {"ln_mxfp8_wide": 1, "gemm_p256_ragged": 1, "gemm_p256_fp8": 1, "attention_stream": 1, "fp8_ln_fold": 0}[k])
         print(f"{name:14s} {128/dt:8.1f} img/s {dt*1e3:6.2f} ms", flush=True)
