@@ -63,6 +63,7 @@ struct Gemm8Args {
     uint8_t* q_scale;
     float* stats_out;
     int ld_qs;
+    int stagger;            // EXPERIMENTS builds only (option gemm_p256_stagger): odd workgroups sleep `stagger` x ~4 us before they start
 };
 
 // bytes per row of a permuted scale array for K columns

@@ -106,6 +106,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     const int npair = nt >> 1;      // even
     const int ngrp = nt >> 2;       // 512-k scale groups per tile
     __builtin_assume(npair >= 2);   // (K >= 512: no zero-trip copies of the K loop, whose accumulator joins cost registers)
+#ifdef MMISS_EXPERIMENTS
+    // timing experiment (profiles/gemm_fp8_p256_r05.txt): do the workgroups' epilogues cost more because all 256 run them at once?
+    if (g.stagger > 0 && (blockIdx.x & 1))
+        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
     // ---- the ragged last row block, in front of everything (no LDS-DMA is in flight yet: ordinary loads, ordinary waits)
     if (g.ragged > 0) {
@@ -875,6 +880,9 @@ static int launch_gemm256p8(hipStream_t st, int epi, Gemm8Args g, int xt = 0) {
     g.ragged = 0;
     if (g.M >= 512 && g.m_valid > g.M - 256 && g.m_valid <= g.M - 128 && mmiss_option("gemm_p256_ragged", 1) != 0)
         g.ragged = g.m_valid - (g.M - 256);
+#ifdef MMISS_EXPERIMENTS
+    g.stagger = mmiss_option("gemm_p256_stagger", 0);
+#endif
     if (!gemm256p8_xt_ok(epi, xt, g)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "gemm256p8: extension %d of epilogue %d at M=%d N=%d K=%d", xt, epi, g.M, g.N, g.K);
     static const char* names[] = {"gemm_fp8_bias_p256", "gemm_fp8_qgelu_mx_p256", "", "gemm_fp8_bias_resid16_p256"};
     static const char* names_x[] = {"gemm_fp8_lnfold_bias_p256", "gemm_fp8_lnfold_qgelu_mx_p256", "", "gemm_fp8_bias_resid16_mxq_p256"};
