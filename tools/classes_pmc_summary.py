@@ -26,7 +26,7 @@ CLASSES = [  # (class, regex over the kernel name as rocprofv3 prints it — dem
     ("gemm_fp8_bias_p256 (L/14 QKV, fp8)", r"gemm256p8_kernel(ILi0E|<0>)", "fp8"),
     ("gemm_fp8_qgelu_mx_p256 (L/14 FC1, fp8 -> MXFP8)", r"gemm256p8_kernel(ILi1E|<1>)", "fp8"),
     ("gemm_fp8_bias_resid16_p256 (L/14 out-proj + FC2, fp8)", r"gemm256p8_kernel(ILi3E|<3>)", "fp8"),
-    ("attention_long (L/14: 257 tokens, bf16 + MXFP8 output)", r"attention_long_kernel", "fp8"),
+    ("attention_stream (L/14: 257 tokens, bf16 + MXFP8 output; round 5)", r"attention_(stream|long)_kernel", "fp8"),
     ("layernorm16 -> MXFP8 (L/14, 16 columns per lane)", r"layernorm16_mxfp8", "fp8"),
 ]
 COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAVES",
