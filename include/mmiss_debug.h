@@ -110,7 +110,7 @@ int mmiss_dbg_gemm8_time(int device, int epi, int bm, const void* A8, const void
 
 /* bit 0: the library was built with MMISS_EXPERIMENTS (A/B variants kept for timing; the product build rejects them with
  * MMISS_ERR_UNSUPPORTED). bit 1: one of its translation units was built with a timing-experiment macro of tools/(name)_ab.sh
- * (P256_NO_LATE_WAIT, P256_SPLIT_STAGE, P256_STAGE_FIRST, P256_A_POLICY, P256_W_POLICY, P256_PRIO, MMISS_SCAN_NT) — NOT a product build: mmiss_amd._lib.load() refuses it unless
+ * (P256_NO_LATE_WAIT, P256_SPLIT_STAGE, P256_STAGE_FIRST, P256_A_POLICY, P256_W_POLICY, P256_PRIO, MMISS_SCAN_NT, Q256_STAGE_MID) — NOT a product build: mmiss_amd._lib.load() refuses it unless
  * MMISS_ALLOW_AB_BUILD=1, so that no test or bench run is attributed to HEAD by accident. The product build returns 0. */
 int mmiss_dbg_build_flags(void);
 

@@ -1283,7 +1283,7 @@ extern "C" int mmiss_dbg_build_flags(void) {
 #ifdef MMISS_EXPERIMENTS
     f |= 1;
 #endif
-#if defined(P256_NO_LATE_WAIT) || defined(P256_SPLIT_STAGE) || defined(P256_STAGE_FIRST) || defined(P256_A_POLICY) || defined(P256_W_POLICY) || defined(P256_PRIO) || defined(MMISS_SCAN_NT)
+#if defined(P256_NO_LATE_WAIT) || defined(P256_SPLIT_STAGE) || defined(P256_STAGE_FIRST) || defined(P256_A_POLICY) || defined(P256_W_POLICY) || defined(P256_PRIO) || defined(MMISS_SCAN_NT) || defined(Q256_STAGE_MID)
     f |= 2;   // built with a timing-experiment macro (tools/*_ab.sh): NOT a product build
 #endif
     return f;

@@ -418,13 +418,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
         wq[nq][nf][4] = hi_[0]; wq[nq][nf][5] = hi_[1]; wq[nq][nf][6] = hi_[2]; wq[nq][nf][7] = hi_[3];     \
     }
 // 8 block-scaled MFMAs: weights = A operand (unit block scales), activations = B operand (scale byte 0 of sc[mf])
-#define Q256_MMA(mq, nq)                                                                                     \
+// STG = the phase's two LDS-DMA pieces when they are issued from the MIDDLE of the MFMA part (Q256_STAGE_MID: after the first
+// four MFMAs — 24 of an MFMA's 32 cycles are free issue slots of the wave, and the partner half's read part, the longer side of
+// every barrier-to-barrier segment, loses its most expensive instructions), empty otherwise
+#define Q256_MMA(mq, nq, STG)                                                                                \
     {                                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                                      \
-        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                    \
+        _Pragma("unroll") for (int nf = 0; nf < 2; ++nf) {                                                  \
             _Pragma("unroll") for (int mf = 0; mf < 4; ++mf)                                                \
                 acc[(nq) * 2 + nf][(mq) * 4 + mf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(       \
                     wq[nq][nf], am[mf], acc[(nq) * 2 + nf][(mq) * 4 + mf], 0, 0, 0, 0x7F7F7F7F, 0, sc[mf]); \
+            if (nf == 0) {                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+                STG;                                                                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+            }                                                                                               \
+        }                                                                                                   \
         /* pinned: without a use at this point the optimiser sinks the MFMAs (pure functions of registers) behind the */ \
         /* pair's sixteen barriers — every fragment of two K-tiles alive at once, 200+ spilled registers */       \
         _Pragma("unroll") for (int nf = 0; nf < 2; ++nf)                                                    \
@@ -432,8 +441,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
                 asm volatile("" : Q256_PIN(acc[(nq) * 2 + nf][(mq) * 4 + mf]));                                \
         __builtin_amdgcn_s_setprio(0);                                                                      \
     }
+#ifdef Q256_STAGE_MID
+#define Q256_STG_READ(...)
+#define Q256_STG_MMA(...) Q256_STAGE(__VA_ARGS__)
+#define Q256_WADJ 2
+#else
+#define Q256_STG_READ(...) Q256_STAGE(__VA_ARGS__)
+#define Q256_STG_MMA(...)
+#define Q256_WADJ 0
+#endif
 // counted wait: 10 younger slot pieces stay in flight; POST: + the previous tile's epilogue operations; XS: + the pair's scale piece
-#define Q256_WAIT(POST, XS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 + ((POST) ? EX : 0) + ((XS) ? 1 : 0)) : "memory")
+#define Q256_WAIT(POST, XS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 - Q256_WADJ + ((POST) ? EX : 0) + ((XS) ? 1 : 0)) : "memory")
 #define Q256_BARRIER()                       \
     {                                        \
         __builtin_amdgcn_sched_barrier(0);   \
@@ -448,29 +466,31 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     {                                                                                                       \
         Q256_READ_A(B, 0);                                                                                  \
         Q256_READ_W(B, 0);                                                                                  \
-        Q256_STAGE(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0); /* A m1 of K-tile t+1 */                          \
+        Q256_STG_READ(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0); /* A m1 of K-tile t+1 */                       \
         Q256_LATE_READS_DONE();                                                                             \
         Q256_WAIT(P0, X0);                /* retires W n1 of this K-tile */                                 \
         Q256_BARRIER();                                                                                     \
-        Q256_MMA(0, 0);                                                                                     \
+        Q256_MMA(0, 0, Q256_STG_MMA(1, (B) ^ 1, oA1 + mA1, oW1, mA1 != 0));                                 \
         Q256_BARRIER();                                                                                     \
         Q256_READ_W(B, 1);                                                                                  \
-        Q256_STAGE(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                    \
+        Q256_STG_READ(0, B, oA2, oW2, true);       /* A m0 of K-tile t+2 */                                 \
         Q256_LATE_READS_DONE();                                                                             \
         Q256_WAIT(P1, X1);                /* retires A m1 of this K-tile */                                 \
         Q256_BARRIER();                                                                                     \
-        Q256_MMA(0, 1);                                                                                     \
+        Q256_MMA(0, 1, Q256_STG_MMA(0, B, oA2, oW2, true));                                                 \
         Q256_BARRIER();                                                                                     \
         if constexpr (!(HALF)) { Q256_READ_A(B, 1); }                                                       \
-        Q256_STAGE(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
+        Q256_STG_READ(2, B, oA2, oW2, true);       /* W n0 of K-tile t+2; nothing new is read in the next phase: no wait */ \
         Q256_LATE_READS_DONE();                                                                             \
         Q256_BARRIER();                                                                                     \
-        if constexpr (!(HALF)) { Q256_MMA(1, 1); }                                                          \
+        if constexpr (!(HALF)) { Q256_MMA(1, 1, Q256_STG_MMA(2, B, oA2, oW2, true)); }                      \
+        else { Q256_STG_MMA(2, B, oA2, oW2, true); }                                                        \
         Q256_BARRIER();                                                                                     \
-        Q256_STAGE(3, B, oA2, oW2, true);       /* W n1 of K-tile t+2 */                                    \
+        Q256_STG_READ(3, B, oA2, oW2, true);       /* W n1 of K-tile t+2 */                                 \
         Q256_WAIT(P3, X3);                /* retires A m0 / W n0 of the next K-tile */                      \
         Q256_BARRIER();                                                                                     \
-        if constexpr (!(HALF)) { Q256_MMA(1, 0); }                                                          \
+        if constexpr (!(HALF)) { Q256_MMA(1, 0, Q256_STG_MMA(3, B, oA2, oW2, true)); }                      \
+        else { Q256_STG_MMA(3, B, oA2, oW2, true); }                                                        \
         Q256_BARRIER();                                                                                     \
         Q256_ADVANCE();                                                                                     \
     }
@@ -832,6 +852,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
 #undef Q256_BARRIER
 #undef Q256_LATE_READS_DONE
 #undef Q256_KTILE
+#undef Q256_STG_READ
+#undef Q256_STG_MMA
+#undef Q256_WADJ
 #undef Q256_ADVANCE
 #undef Q256_SCALE_PIECE
 
