@@ -81,10 +81,10 @@ def test_persistent_gemm_kernels_do_not_spill():
         text = open(path).read()
         for b in re.split(r"remark: [^\n]*Function Name: ", text)[1:]:
             name = b.split()[0]
-            if not any(k in name for k in ("gemm256p_kernel", "gemm256s_kernel", "gemm160p_kernel", "gemm256p8_kernel")):
+            if not any(k in name for k in ("gemm256p_kernel", "gemm256s_kernel", "gemm160p_kernel", "gemm256p8_kernel", "attention_stream_kernel")):
                 continue
             seen += 1
             scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
             spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
             assert scratch == 0 and spill == 0, (name, scratch, spill)
-    assert seen >= 12, seen
+    assert seen >= 17, seen   # (round 5: + three extensions of the fp8 kernel, two forms of the streaming attention)

@@ -1,5 +1,5 @@
 """Per-kernel table (instrumented replay: HIP events around every launch) of one ViT-L/14 bs-128 fp8 encode, for an option set:
-python tools/l14_kernel_table.py [key=value ...]"""
+python tools/l14_kernel_table.py [precision=bf16] [key=value ...]"""
 import sys
 sys.path.insert(0, "/root/repo")
 import torch
@@ -10,10 +10,14 @@ enc = ClipEncoder(LONGCLIP_L14, device=0, max_batch_image=128, max_batch_text=8)
 enc.load_state_dict(random_state_dict(LONGCLIP_L14, seed=0))
 x = torch.randn(128, 3, 224, 224, device="cuda")
 o = torch.empty(128, 768, device="cuda")
-enc.set_precision("fp8")
+prec = "fp8"
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
-    _lib.set_option(k, int(v))
+    if k == "precision":
+        prec = v
+    else:
+        _lib.set_option(k, int(v))
+enc.set_precision(prec)
 for _ in range(3):
     enc.encode_image(x, out=o)
 torch.cuda.synchronize()
