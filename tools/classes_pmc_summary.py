@@ -23,9 +23,9 @@ CLASSES = [  # (class, regex over the kernel name as rocprofv3 prints it — dem
     ("gemm_bf16_bias_resid16_p160_k4096 (L/14 FC2, bf16 leg)", r"gemm160p_kernel(ILi9ELi0ELi64E|<9, 0, 64>)", "fp8"),
     ("gemm8 (fp8 block-scaled GEMMs on the BM x 128 tile, round 4; L/14 bs 128)", r"gemm8_kernel", "fp8"),
     # round 5: the persistent 256 x 256 block-scaled fp8 kernel (gemm_fp8_p256.h), one class per epilogue
-    ("gemm_fp8_bias_p256 (L/14 QKV, fp8)", r"gemm256p8_kernel(ILi0E|<0>)", "fp8"),
-    ("gemm_fp8_qgelu_mx_p256 (L/14 FC1, fp8 -> MXFP8)", r"gemm256p8_kernel(ILi1E|<1>)", "fp8"),
-    ("gemm_fp8_bias_resid16_p256 (L/14 out-proj + FC2, fp8)", r"gemm256p8_kernel(ILi3E|<3>)", "fp8"),
+    ("gemm_fp8_bias_p256 (L/14 QKV, fp8)", r"gemm256p8_kernel(ILi0ELi0E|<0, 0>)", "fp8"),
+    ("gemm_fp8_qgelu_mx_p256 (L/14 FC1, fp8 -> MXFP8)", r"gemm256p8_kernel(ILi1ELi0E|<1, 0>)", "fp8"),
+    ("gemm_fp8_bias_resid16_p256 (L/14 out-proj + FC2, fp8)", r"gemm256p8_kernel(ILi3ELi0E|<3, 0>)", "fp8"),
     ("attention_stream (L/14: 257 tokens, bf16 + MXFP8 output; round 5)", r"attention_(stream|long)_kernel", "fp8"),
     ("layernorm16 -> MXFP8 (L/14, 16 columns per lane)", r"layernorm16_mxfp8", "fp8"),
 ]
