@@ -94,6 +94,7 @@ ViT-L/14 bs-128 encode in bf16 and fp8); this section is generated from them by 
 | `{TAG}_bench_line.json` | the JSON line of `python bench.py` (defaults: N = 1, {d['steps']} steps, {d['warmup']} warm-up) |
 | `{TAG}_bench_kernel_stats.csv`, `{TAG}_bench_domain_stats.csv` | `rocprofv3 --kernel-trace --stats` of the step (`bench.py --steps {d['steps']} --warmup {d['warmup']} --retrieval-rows 0 --no-cpu-baseline --no-kernel-events --no-text`) |
 | `{TAG}_retrieval_kernel_stats.csv` | the same for cosine top-10 over 10M × 512 f16 at Q = 1 and Q = 1024 (`tools/retrieval_profile.py`) |
+| `{TAG}_l14_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of the ViT-L/14 bs-128 encode, bf16 then fp8 (`tools/l14_fp8_bench.py`): the per-kernel averages the instrumented replay of the bench line (`l14.fp8.kernels_image_bs128`) must agree with — `gemm256p8_kernel<0 / 1 / 3, 0>`, `attention_stream_kernel<true>` |
 | `{TAG}_traffic.json`, `{TAG}_traffic_retrieval.json` | fabric bytes per launch and kernel class: `--pmc FETCH_SIZE` (× 2, gfx950) + `--pmc WRITE_SIZE`, separate runs over the bench step and over `tools/retrieval_profile.py` (`tools/traffic_from_pmc.py`) |
 | `{TAG}_gemm_pmc_summary.csv` | per kernel class: SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_INST_ANY, SQ_LDS_BANK_CONFLICT, SQ_WAVE_CYCLES, SQ_WAVES, GRBM_GUI_ACTIVE; second pass SQ_INST_CYCLES_VMEM_RD / _WR (gfx950 has no SQ_INST_CYCLES_VMEM), SQ_INSTS_VMEM_RD / _WR, SQ_ACTIVE_INST_VMEM, SQ_WAIT_INST_LDS, SQ_ACTIVE_INST_LDS — the four GEMM classes of the step, attention, the step's score GEMM, and from the L/14 run the bf16 GEMM classes, the fp8 persistent kernel per epilogue (`gemm256p8_kernel`, round 5) and the 257-token attention (`tools/classes_pmc_summary.py`) |
 | `gemm_fp8_p256_r05.txt`, `host_staging_r05.txt`, `boundary_overlap_r05.txt`, `query_q1_r05.txt` | (round 5) the fp8 GEMMs of ViT-L/14 on the tile kernel and on the persistent kernel (ragged block as a pass / as a tile); host inputs through the pinned ring vs pageable `hipMemcpyAsync`; kernel boundaries overlapped through a second stream; the one-query merge experiments |
