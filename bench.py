@@ -47,7 +47,7 @@ KERNEL_SYMBOL = {  # libmmiss kernel class -> symbol as rocprofv3 --kernel-trace
     "gemm_bf16_lnfold_bias_p256": "gemm256p_kernel<7,K/256,0,0>", "gemm_bf16_lnfold_qgelu_p256": "gemm256p_kernel<8,K/256,0,0>",
     "gemm_bf16_bias_p256": "gemm256p_kernel<1,0,0,0>", "gemm_bf16_bias_qgelu_p256": "gemm256p_kernel<2,0,0,0>",
     "gemm_bf16_patch": "gemm16_kernel<__bf16,BM,4>", "score_gemm_f16": "gemm16_kernel<_Float16,128,5>",
-    "attention": "attention_heads_kernel<2,false,4> (short sequences at large batch) / attention_kernel<NKP,causal> / attention_long_kernel<NKP,causal,mx> (> 128 keys) / attention_stream_kernel<mx> (257 keys, >= 512 (item, head) pairs: round 5)",
+    "attention": "attention_heads_kernel<2,false,4> (short sequences at large batch) / attention_kernel<NKP,causal> / attention_long_kernel<NKP,causal,mx> (> 128 keys) / attention_stream_kernel<mx> (257 keys, >= 256 (item, head) pairs: round 5)",
     "layernorm": "layernorm_kernel<true>", "im2col": "im2col_kernel<false>",
     "scan_topk_f16": "scan_topk_kernel<_Float16,...>", "scan_topk_f32": "scan_topk_kernel<float,...>",
 }

@@ -1,4 +1,4 @@
-// attention_stream.h — K4 for the ViT-L/14 regime (257 keys = 16 x 16 + 1, non-causal, >= 512 (item, head) pairs): one persistent
+// attention_stream.h — K4 for the ViT-L/14 regime (257 keys = 16 x 16 + 1, non-causal, >= 256 (item, head) pairs): one persistent
 // workgroup of 16 waves per CU walks its (item, head) pairs with the NEXT pair's K/V rows arriving by LDS-DMA while the
 // current pair is computed.
 //
@@ -55,7 +55,10 @@ __device__ __forceinline__ void ats_dma4(u32x4 srd, uint32_t lds, int vo) {
 }
 
 static inline bool attention_stream_ok(int B, int T, int H, bool causal) {
-    return !causal && T == ATS_T && (int64_t)B * H >= 512 && H > 0 && (int64_t)T * 6 * H * 64 < (1ll << 31);
+    // enough (item, head) pairs for every CU to stream a few: below that attention_long_kernel's query-tile splits fill the chip better
+    // (option attention_stream_min_pairs, default 256: measured, profiles/attention_stream_r05.txt)
+    return !causal && T == ATS_T && (int64_t)B * H >= mmiss_option("attention_stream_min_pairs", 256) && H > 0 &&
+           (int64_t)T * 6 * H * 64 < (1ll << 31);
 }
 
 template <bool MXOUT>

@@ -37,7 +37,8 @@ def run(B, H, stream, mx):
     return res, best, qkv
 
 
-for B, H in ((128, 16), (64, 16), (33, 16), (43, 12)):
+_lib.set_option("attention_stream_min_pairs", 1)
+for B, H in ((128, 16), (64, 16), (33, 16), (43, 12), (24, 16), (16, 16), (8, 16), (4, 16), (1, 16)):
     for mx in (0, 1):
         old, t_old, qkv = run(B, H, 0, mx)
         new, t_new, _ = run(B, H, 1, mx)
