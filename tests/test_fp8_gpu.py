@@ -121,7 +121,7 @@ def test_layernorm_mxfp8_from_bf16_rows(env, d):
     assert (np.abs(back - y) <= gmax * 2.0 ** -4 * 1.01 + 1e-6).all()
 
 
-@pytest.mark.parametrize("B,T,H", [(3, 257, 16), (2, 200, 4)])
+@pytest.mark.parametrize("B,T,H", [(3, 257, 16), (2, 200, 4), (33, 257, 16), (43, 257, 12)])   # (the last two: attention_stream_kernel, 2-3 pairs per workgroup)
 def test_attention_with_mxfp8_output(env, B, T, H):
     """The fp8 vision tower's attention writes its output as MXFP8 (the out-projection's A operand on the fp8 GEMM): the
     dequantised bytes must equal the bf16-output kernel's rows up to the e4m3 rounding of a block — 2^-4 of the block's

@@ -291,7 +291,7 @@ def _attn_ref(torch, qkv, B, T, H, causal):
 
 @pytest.mark.parametrize("B,T,H,causal", [(3, 50, 12, 0), (2, 77, 8, 1), (2, 16, 2, 1), (1, 5, 2, 0), (2, 257, 4, 0), (1, 248, 3, 1), (5, 33, 2, 1),
                                             (2, 150, 2, 1), (1, 288, 2, 0), (40, 129, 16, 0),
-                                            (64, 257, 16, 0), (128, 130, 12, 1)])
+                                            (64, 257, 16, 0), (128, 130, 12, 1), (43, 257, 12, 0), (16, 257, 16, 0)])   # (257 keys from 256 pairs on: attention_stream_kernel)
 def test_attention(env, B, T, H, causal):
     torch, _lib, lib = env
     g = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
@@ -472,3 +472,36 @@ def test_gemm_p160_resid16(env, M, N, K, mv):
         if mv < M:   # pad rows: untouched except the dump row M - 1; their statistics are not written
             assert torch.equal(out[mv:M - 1].view(torch.int16), x0[mv:M - 1].view(torch.int16))
             assert torch.isnan(st[mv:]).all()
+
+
+def test_streaming_attention_equals_the_split_form_on_the_full_tiles(env):
+    """attention_stream_kernel (round 5: 257 keys, >= 256 (item, head) pairs; persistent workgroups, the next pair's K/V by LDS-DMA,
+    the 257th query merged from nine partial softmaxes) against attention_long_kernel on the same input: the 256 queries of the
+    16 full tiles run the same instructions in the same order — equal bytes —, the last query within the bf16 tolerance of the
+    fp32 softmax; with and without the rescale branch forced (spiked keys), and a pair count that is not a multiple of the grid."""
+    torch, _lib, lib = env
+    B, T, H = 35, 257, 16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qkv = torch.randn(B * T, 3 * H * 64, device="cuda", generator=g) * 0.7
+    x = qkv.view(B, T, 3, H, 64)
+    x[:, :, 0, :, 0] = 3.0
+    for key, val in ((40, 20.0), (133, 70.0), (256, 150.0)):   # growing spikes, the last one on the lone key of the 17th tile
+        x[: B // 2, key, 1, :, 0] = val
+    qkv = _bf16(qkv)
+    outs = []
+    try:
+        for stream in (0, 1):
+            _lib.set_option("attention_stream", stream)
+            ctx = torch.zeros(B * T, H * 64, device="cuda", dtype=torch.bfloat16)
+            _lib.check(lib.mmiss_dbg_attention(0, None, qkv.data_ptr(), ctx.data_ptr(), B, T, H, 0))
+            torch.cuda.synchronize()
+            outs.append(ctx)
+    finally:
+        _lib.set_option("attention_stream", 1)
+    rows = torch.arange(B * T, device="cuda") % T
+    full = rows < 256
+    assert torch.equal(outs[0][full], outs[1][full])
+    ref = _attn_ref(torch, qkv, B, T, H, False)
+    for o in outs:
+        assert torch.isfinite(o.float()).all()
+        assert (o.float() - ref).abs().max().item() < 2e-2
