@@ -208,24 +208,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
             const size_t row = (size_t)b * T + (q < T ? q : 0);
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
-                float o[2][4];
+                // (the block maximum of the UNNORMALISED outputs times 1 / l, and one multiplier 2^-e / l per value: the same bits as
+                // normalising first — scaling by a power of two commutes with the rounding — for half the multiplies)
                 float amax = 0.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        o[i][r] = oacc[2 * blk + i][r] * inv;
-                        amax = fmaxf(amax, fabsf(o[i][r]));
-                    }
-                amax = ats_max_over_lane_groups(amax);
+                    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(oacc[2 * blk + i][r]));
+                amax = ats_max_over_lane_groups(amax) * inv;
                 int e8;
                 float sinv;
                 mx_scale_of(amax, e8, sinv);
+                sinv *= inv;
                 if (q < T) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         *reinterpret_cast<uint32_t*>(ctx8 + row * dmodel + h * 64 + (2 * blk + i) * 16 + 4 * fg) =
-                            pack_fp8x4(o[i][0] * sinv, o[i][1] * sinv, o[i][2] * sinv, o[i][3] * sinv);
+                            pack_fp8x4(oacc[2 * blk + i][0] * sinv, oacc[2 * blk + i][1] * sinv, oacc[2 * blk + i][2] * sinv, oacc[2 * blk + i][3] * sinv);
                     if (fg == 0) ctxs[row * ld_s + mx_scale_offset(2 * h + blk)] = (uint8_t)e8;
                 }
             }
