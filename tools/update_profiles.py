@@ -97,7 +97,7 @@ ViT-L/14 bs-128 encode in bf16 and fp8); this section is generated from them by 
 | `{TAG}_l14_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats` of the ViT-L/14 bs-128 encode, bf16 then fp8 (`tools/l14_fp8_bench.py`): the per-kernel averages the instrumented replay of the bench line (`l14.fp8.kernels_image_bs128`) must agree with — `gemm256p8_kernel<0 / 1 / 3, 0>`, `attention_stream_kernel<true>` |
 | `{TAG}_traffic.json`, `{TAG}_traffic_retrieval.json` | fabric bytes per launch and kernel class: `--pmc FETCH_SIZE` (× 2, gfx950) + `--pmc WRITE_SIZE`, separate runs over the bench step and over `tools/retrieval_profile.py` (`tools/traffic_from_pmc.py`) |
 | `{TAG}_gemm_pmc_summary.csv` | per kernel class: SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_INST_ANY, SQ_LDS_BANK_CONFLICT, SQ_WAVE_CYCLES, SQ_WAVES, GRBM_GUI_ACTIVE; second pass SQ_INST_CYCLES_VMEM_RD / _WR (gfx950 has no SQ_INST_CYCLES_VMEM), SQ_INSTS_VMEM_RD / _WR, SQ_ACTIVE_INST_VMEM, SQ_WAIT_INST_LDS, SQ_ACTIVE_INST_LDS — the four GEMM classes of the step, attention, the step's score GEMM, and from the L/14 run the bf16 GEMM classes, the fp8 persistent kernel per epilogue (`gemm256p8_kernel`, round 5) and the 257-token attention (`tools/classes_pmc_summary.py`) |
-| `gemm_fp8_p256_r05.txt`, `host_staging_r05.txt`, `boundary_overlap_r05.txt`, `query_q1_r05.txt` | (round 5) the fp8 GEMMs of ViT-L/14 on the tile kernel and on the persistent kernel (ragged block as a pass / as a tile); host inputs through the pinned ring vs pageable `hipMemcpyAsync`; kernel boundaries overlapped through a second stream; the one-query merge experiments |
+| `gemm_fp8_p256_r05.txt`, `attention_stream_r05.txt`, `host_staging_r05.txt`, `boundary_overlap_r05.txt`, `query_q1_r05.txt` | (round 5) the fp8 GEMMs of ViT-L/14 on the tile kernel and on the persistent kernel (ragged block as a pass / as a tile), and what was measured on that kernel afterwards — workgroups out of step, the LayerNorm folded in (kernel table), LDS-DMA pieces from the MFMA part, packed QuickGELU, K-tiles per trip of the ragged pass, band height of the tile order (also for the headline's bf16 GEMMs); the streaming 257-token attention against the round-4 kernel (isolated, inside the encode, small batches, wave priority, compiler notes); host inputs through the pinned ring vs pageable `hipMemcpyAsync`; kernel boundaries overlapped through a second stream; the one-query merge experiments |
 | `gemm_p256_r03.txt` | (round 3) what was measured while the persistent 256² kernel, the (removed) stream-K kernel and the 160 × 256 kernel were built |
 | `attention_l14_r04.txt`, `query_q1_r04.txt` | (round 4) the long attention kernel ablated (K/V staging alone, query tiles alone, waves per workgroup, the removed register prefetch) and the one-query options (scan slabs, merge levels) |
 
