@@ -619,6 +619,9 @@ int run_head(mmiss_encoder* e, Tower& tw, int B, float* out_dev, hipStream_t st)
 
 int encode_image_chunk(mmiss_encoder* e, const void* pix_dev, bool src_u8, int B, float* out_dev, hipStream_t st) {
     Tower& tw = e->vis;
+    // "the embedding stage already left xb + row statistics" is said by THIS call's embedding stage only: a call that failed between
+    // setting and consuming the flags must not make the next one fold stale statistics
+    tw.embed_stats = tw.embed_stats16 = false;
     const int d = tw.hidden, S = e->cfg.v_image, P = e->cfg.v_patch;
     const int Mpatch = B * e->G * e->G;
     const int bm_p = gemm_pick_variant(Mpatch, d);
@@ -727,7 +730,11 @@ static int enc_h2d(mmiss_encoder* enc, void* dst, const void* src, size_t bytes,
             const int hw = (int)std::thread::hardware_concurrency();
             int nthr = mmiss_option("stage_threads", 0);
             if (nthr <= 0) nthr = hw >= 2 ? (hw / 2 < 8 ? hw / 2 : 8) : 1;
-            MM_TRY(enc->stager.init((size_t)mmiss_option("stage_block_mb", 16) << 20, nthr));
+            if (nthr > (hw > 0 ? hw : 1)) nthr = hw > 0 ? hw : 1;
+            if (nthr > 64) nthr = 64;
+            int mb = mmiss_option("stage_block_mb", 16);
+            mb = mb < 1 ? 1 : (mb > 256 ? 256 : mb);
+            MM_TRY(enc->stager.init((size_t)mb << 20, nthr));
         }
         return enc->stager.h2d(dst, src, bytes, stream);
     }

@@ -453,6 +453,10 @@ extern "C" int mmiss_index_remove(mmiss_index* ix, const int64_t* labels, int64_
         std::swap(ix->labels_d.p, nlab.p); std::swap(ix->labels_d.bytes, nlab.bytes);
         std::swap(ix->inv.p, ninv.p); std::swap(ix->inv.bytes, ninv.bytes);
     }
+    else if (ix->dtype == MMISS_F8 && ix->capacity > 0) {   // every row removed: the inverse norms stay zero behind `count` (mmiss_index_clear's invariant)
+        MM_HIP(hipMemsetAsync(ix->inv.p, 0, (size_t)ix->capacity * 4, st));
+        MM_HIP(hipStreamSynchronize(st));
+    }
     ix->labels_h.swap(nl);
     ix->count = keep;
     return MMISS_OK;
@@ -1166,12 +1170,24 @@ extern "C" int mmiss_index_load(mmiss_index* ix, const char* path) {
         MM_FAIL(MMISS_ERR_ARG, "%s holds dim %d dtype %d; this index is dim %d dtype %d", path, h.dim, h.dtype, ix->dim,
                 ix->dtype);
     }
+    const size_t row_bytes = (size_t)ix->dim * ix->elt;
+    {   // a truncated file is refused BEFORE anything of the index is overwritten: the header's count against the file's length
+        const long at = ftell(f);
+        long end = -1;
+        if (at >= 0 && fseek(f, 0, SEEK_END) == 0) end = ftell(f);
+        if (at < 0 || end < 0 || fseek(f, at, SEEK_SET) != 0) { fclose(f); MM_FAIL(MMISS_ERR_IO, "cannot seek in %s", path); }
+        if ((uint64_t)h.count > (uint64_t)(end - at) / (8 + row_bytes)) {
+            fclose(f);
+            MM_FAIL(MMISS_ERR_IO, "%s is truncated or corrupt (%ld bytes behind the header, %lld rows need %llu); the index is unchanged",
+                    path, end - at, (long long)h.count, (unsigned long long)((uint64_t)h.count * (8 + row_bytes)));
+        }
+    }
     std::vector<int64_t> lab((size_t)h.count);
     bool ok = h.count == 0 || fread(lab.data(), 8, (size_t)h.count, f) == (size_t)h.count;
     for (int64_t i = 1; ok && i < h.count; ++i) ok = lab[i] > lab[i - 1];
-    int rc = MMISS_OK;
-    if (ok) rc = index_reserve(ix, h.count, st);
-    const size_t row_bytes = (size_t)ix->dim * ix->elt;
+    if (!ok) { fclose(f); MM_FAIL(MMISS_ERR_IO, "%s: labels unreadable or not strictly increasing; the index is unchanged", path); }
+    int rc = index_reserve(ix, h.count, st);
+    if (rc != MMISS_OK) { fclose(f); return rc; }
     const int64_t chunk = std::max<int64_t>(1, (64 << 20) / (int64_t)row_bytes);
     std::vector<char> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(h.count, 1)) * row_bytes);
     for (int64_t r0 = 0; ok && rc == MMISS_OK && r0 < h.count; r0 += chunk) {
@@ -1181,8 +1197,14 @@ extern "C" int mmiss_index_load(mmiss_index* ix, const char* path) {
                             hipMemcpyHostToDevice) != hipSuccess) ok = false;
     }
     fclose(f);
-    if (rc != MMISS_OK) return rc;
-    if (!ok) MM_FAIL(MMISS_ERR_IO, "%s is truncated or corrupt", path);
+    if (!ok) {
+        // a read or copy error with part of the rows already overwritten: old labels / inverse norms no longer describe what the
+        // buffer holds, so the index is left EMPTY rather than inconsistent
+        if (ix->dtype == MMISS_F8 && ix->capacity > 0) { (void)hipMemsetAsync(ix->inv.p, 0, (size_t)ix->capacity * 4, st); (void)hipStreamSynchronize(st); }
+        ix->count = 0;
+        ix->labels_h.clear();
+        MM_FAIL(MMISS_ERR_IO, "%s could not be read to its end; the index was cleared", path);
+    }
     if (h.count) MM_HIP(hipMemcpy(ix->labels_d.p, lab.data(), (size_t)h.count * 8, hipMemcpyHostToDevice));
     // fp8 rows: the file holds the codes only; their inverse norms are a function of the codes (files of round 4 load as they are)
     if (ix->dtype == MMISS_F8 && ix->capacity > 0) {

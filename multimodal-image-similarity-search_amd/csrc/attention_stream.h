@@ -47,11 +47,14 @@ __device__ __forceinline__ float ats_max_over_lane_groups(float v) {   // max ov
 // one 1 KB (16 B per lane) / 256 B (4 B per lane) piece global -> LDS. Inline asm on purpose: behind the builtin hipcc puts an
 // s_waitcnt vmcnt in front of the first transposing LDS read that follows (it cannot tell the two images apart) — a drain
 // of the prefetch at the head of every pair. The waits are ours: vmcnt(0) before the barrier that hands an image over.
+// m0 is a reserved register: hipcc ignores it in a clobber list (and says so), so it is NOT listed. What makes writing it safe
+// is that nothing else in this kernel may depend on it — tests/test_abi_cpu.py disassembles the kernel and holds every
+// instruction that touches m0 to be one of these asm statements' own (s_mov_b32 m0 / s_nop 0 / buffer_load ... lds).
 __device__ __forceinline__ void ats_dma16(u32x4 srd, uint32_t lds, int vo) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(vo), "s"(srd) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(vo), "s"(srd) : "memory");
 }
 __device__ __forceinline__ void ats_dma4(u32x4 srd, uint32_t lds, int vo) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds), "v"(vo), "s"(srd) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds), "v"(vo), "s"(srd) : "memory");
 }
 
 static inline bool attention_stream_ok(int B, int T, int H, bool causal) {

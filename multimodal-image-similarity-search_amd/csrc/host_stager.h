@@ -42,8 +42,7 @@ struct HostStager {
         memcpy(dst + lo, src + lo, len);
     }
 
-    void worker(int id) {
-        int seen = 0;
+    void worker(int id, int seen) {   // seen = the generation at the time the pool was started (a re-initialised ring must not replay the last job)
         for (;;) {
             char* d; const char* s; size_t n;
             {
@@ -61,15 +60,25 @@ struct HostStager {
         }
     }
 
-    int init(size_t block_bytes, int threads) {
-        if (slot_bytes) return MMISS_OK;
+    int init_blocks(size_t block_bytes) {
         for (int i = 0; i < NSLOT; ++i) {
             MM_HIP(hipHostMalloc(reinterpret_cast<void**>(&pin[i]), block_bytes, hipHostMallocDefault));
             MM_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         }
+        return MMISS_OK;
+    }
+    // block_bytes in [1 MB, 256 MB], threads in [1, 64] (the caller clamps the options to that; anything else is refused: a
+    // zero block would never advance h2d's loop). A ring that fails part-way is torn down again, nothing is left pinned.
+    int init(size_t block_bytes, int threads) {
+        if (slot_bytes) return MMISS_OK;
+        if (block_bytes < ((size_t)1 << 20) || block_bytes > ((size_t)256 << 20) || threads < 1 || threads > 64)
+            MM_FAIL(MMISS_ERR_ARG, "pinned staging ring: block of %zu bytes / %d threads outside 1..256 MB / 1..64", block_bytes, threads);
+        const int rc = init_blocks(block_bytes);
+        if (rc != MMISS_OK) { shutdown(); return rc; }
         slot_bytes = block_bytes;
-        nthreads = threads < 1 ? 1 : threads;
-        for (int t = 1; t < nthreads; ++t) workers.emplace_back([this, t] { worker(t); });   // (the caller is slice 0)
+        stop = false;
+        nthreads = threads;
+        for (int t = 1; t < nthreads; ++t) workers.emplace_back([this, t, g0 = job_gen] { worker(t, g0); });   // (the caller is slice 0)
         return MMISS_OK;
     }
 
@@ -90,6 +99,7 @@ struct HostStager {
     // dst_dev[0, bytes) = src_host[0, bytes), queued on `stream`; returns once the last block's host copy is done (its bytes
     // may still be crossing the link: stream order covers every consumer on `stream` or behind an event recorded on it)
     int h2d(void* dst_dev, const void* src_host, size_t bytes, hipStream_t stream) {
+        if (!slot_bytes) MM_FAIL(MMISS_ERR_ARG, "pinned staging ring used before init");
         const char* src = reinterpret_cast<const char*>(src_host);
         char* dst = reinterpret_cast<char*>(dst_dev);
         for (size_t off = 0; off < bytes; off += slot_bytes) {
@@ -116,7 +126,9 @@ struct HostStager {
         for (int i = 0; i < NSLOT; ++i) {
             if (done[i]) { (void)hipEventSynchronize(done[i]); (void)hipEventDestroy(done[i]); done[i] = nullptr; }
             if (pin[i]) { (void)hipHostFree(pin[i]); pin[i] = nullptr; }
+            used[i] = false;
         }
+        next_slot = 0;
         slot_bytes = 0;
     }
     ~HostStager() { shutdown(); }

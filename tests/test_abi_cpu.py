@@ -88,3 +88,62 @@ def test_persistent_gemm_kernels_do_not_spill():
             spill = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
             assert scratch == 0 and spill == 0, (name, scratch, spill)
     assert seen >= 17, seen   # (round 5: + three extensions of the fp8 kernel, two forms of the streaming attention)
+
+
+def _gfx950_disassembly(obj_name, tmp_path):
+    """The gfx950 code object of csrc/<obj_name>.o, disassembled: {kernel symbol: [instruction text, ...]}."""
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    src = os.path.join(ROOT, "multimodal-image-similarity-search_amd", "csrc", obj_name + ".o")
+    if not os.path.exists(src) or not os.path.exists(objdump):
+        pytest.skip("no object file / no llvm-objdump: the library was not built by csrc/Makefile in this tree")
+    work = str(tmp_path)
+    shutil.copy(src, work)
+    subprocess.check_call([objdump, "--offloading", obj_name + ".o"], cwd=work, stdout=subprocess.DEVNULL)   # writes the bundles next to the copy
+    co = [f for f in os.listdir(work) if "gfx950" in f]
+    assert len(co) == 1, os.listdir(work)
+    text = subprocess.check_output([objdump, "-d", co[0]], cwd=work, text=True)
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif cur is not None and line.startswith("\t"):
+            cur.append(line.split("//")[0].strip())
+    return kernels
+
+
+def test_streaming_attention_owns_every_use_of_m0(tmp_path):
+    """attention_stream.h issues its LDS-DMA pieces from inline asm that writes m0 (the LDS destination of `buffer_load ... lds`).
+    m0 is reserved: hipcc ignores it in a clobber list, so nothing tells the compiler it changed. That is safe only while no
+    other instruction of the kernel depends on m0 — enforced here on the ISA: every instruction that names m0 is the
+    `s_mov_b32 m0` of one asm statement, followed by that statement's own `s_nop 0` and `buffer_load ... lds`; every LDS-DMA
+    load has such a head; nothing with an implicit m0 operand (s_movrel, ds_gws, s_sendmsg, interpolation) appears."""
+    kernels = _gfx950_disassembly("api_encoder", tmp_path)
+    mine = {k: v for k, v in kernels.items() if "attention_stream_kernel" in k}
+    assert len(mine) == 2, sorted(mine)          # bf16 and MXFP8 output
+    for name, ins in mine.items():
+        heads = dma = 0
+        for i, text in enumerate(ins):
+            op = text.split()[0]
+            assert not op.startswith(("s_movrel", "v_movrel", "ds_gws", "s_sendmsg", "v_interp", "s_load_dword_m0")), (name, text)
+            if op.startswith("buffer_load") and text.endswith(" lds"):
+                dma += 1
+                assert ins[i - 1] == "s_nop 0" and ins[i - 2].startswith("s_mov_b32 m0, "), (name, ins[i - 3:i + 1])
+            if re.search(r"\bm0\b", text):
+                assert op == "s_mov_b32" and text.startswith("s_mov_b32 m0, "), (name, text)      # never read, never written otherwise
+                assert ins[i + 1] == "s_nop 0" and ins[i + 2].startswith("buffer_load") and ins[i + 2].endswith(" lds"), (name, ins[i:i + 3])
+                heads += 1
+        assert heads == dma and dma >= 8, (name, heads, dma)
+
+
+def test_build_log_has_no_inline_asm_warnings():
+    """`clobber list contains reserved registers` (-Winline-asm) was 24 warnings per build while attention_stream.h listed m0."""
+    for obj in ("api_encoder", "api_index", "runtime"):
+        path = os.path.join(ROOT, "multimodal-image-similarity-search_amd", "csrc", obj + ".resources.txt")
+        if not os.path.exists(path):
+            pytest.skip("no build log: the library was not built by csrc/Makefile in this tree")
+        text = open(path).read()
+        assert "-Winline-asm" not in text and "reserved registers" not in text, obj

@@ -52,5 +52,9 @@ def test_bench_one_gpu_pipelined_steps_deliver_the_synchronous_results():
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
     assert "query_begin" in cfg["step_pipelining"] and cfg["ms_per_step_unpipelined"] > 0
     assert cfg["last_pipelined_result_equals_synchronous_query"] is True
-    assert out["exactness"]["queries"] >= (2 + 3 + 3 + 3) * 256 and out["exactness"]["widened"] == 0
+    # round 6: `value` is timed on configs[1] AS WRITTEN — the index holds the embeddings of the step's own images, every query is
+    # a row of it (and must come back first), and the exactness guard widens them (random-weight embeddings: pairwise cosine 0.99)
+    assert "THESE images" in cfg["workload"] and cfg["every_query_of_the_last_step_finds_itself_first"] is True
+    assert cfg["max_self_distance_last_step"] < 1e-5
+    assert out["exactness"]["queries"] == 3 * 256 and out["exactness"]["widened"] > 0
     assert out["roofline"]["kernel"].startswith("gemm_bf16_") and 0 < out["roofline"]["frac"] < 1

@@ -403,3 +403,55 @@ def test_single_request_runs_without_layernorm_launches(b32):
           % (d_img, d_txt, (1 - _cos(out1, plain1)).max()))
     assert d_img < COS_TOL and d_txt < COS_TOL
     assert (1 - _cos(out1, plain1)).max() < 2e-5
+
+
+def test_pinned_staging_ring_delivers_the_default_path_bits():
+    """Option pinned_stage = 1 (csrc/host_stager.h: a ring of pinned blocks filled by worker threads) is a different ROUTE for
+    host-resident inputs of 4 MB and more, not different arithmetic: float32 pixels, uint8 crops and raw RGB uploads must give
+    the bytes of the default route (hipMemcpyAsync from the caller's memory). Sizes chosen so that a chunk spans several ring
+    blocks (1 MB blocks, 3 threads: slices, wrap-around of the four slots, a ragged last block) and several chunks per call."""
+    import dataclasses
+
+    import mmiss_amd  # noqa: F401
+    from mmiss_amd import _lib
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+    from oracle import clip_oracle as co
+
+    s = dataclasses.replace(co.TINY, v_image=224)          # 7 x 7 patches + CLS; 602 KB of float32 per image
+    W = co.init_weights(s, seed=11)
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=32, max_batch_text=2)
+    enc.load_state_dict(W)
+    rng = np.random.Generator(np.random.Philox(12))
+    px = rng.standard_normal((75, 3, 224, 224), dtype=np.float32)                   # 45 MB: chunks of 32, 32, 11 images
+    u8 = rng.integers(0, 256, size=(75, 224, 224, 3), dtype=np.uint8)               # 11 MB; 4.8 MB per full chunk
+    raw = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in [(480, 640), (300, 500), (224, 224), (700, 333)] * 12]   # 28 MB
+    got = {}
+    try:
+        for ring in (0, 1):
+            _lib.set_option("pinned_stage", ring)
+            _lib.set_option("stage_block_mb", 1)
+            _lib.set_option("stage_threads", 3)
+            got[ring] = (enc.encode_image(px), enc.encode_image(u8), enc.encode_image_rgb(raw))
+    finally:
+        _lib.set_option("pinned_stage", 0)
+        _lib.set_option("stage_block_mb", 16)
+        _lib.set_option("stage_threads", 0)
+    for a, b in zip(got[0], got[1]):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    ref = co.embed_images(px[[0, 40, 74]], W, s)
+    assert (1 - _cos(got[1][0][[0, 40, 74]], ref)).max() < COS_TOL
+    # a second handle with out-of-range knobs: clamped (a zero block would never advance the copy loop), same bits
+    enc2 = ClipEncoder(ClipShape.from_any(s), max_batch_image=32, max_batch_text=2)
+    enc2.load_state_dict(W)
+    try:
+        _lib.set_option("pinned_stage", 1)
+        _lib.set_option("stage_block_mb", 0)
+        _lib.set_option("stage_threads", 1000)
+        again = enc2.encode_image(px)
+    finally:
+        _lib.set_option("pinned_stage", 0)
+        _lib.set_option("stage_block_mb", 16)
+        _lib.set_option("stage_threads", 0)
+    assert np.array_equal(again.view(np.uint32), got[0][0].view(np.uint32))
+    enc.close()
+    enc2.close()

@@ -216,10 +216,11 @@ def test_l14_width_fp8_outlier_hidden_channels():
 
 def test_l14_full_depth_outlier_channels_measured():
     """The same +300 / -180 residual channels through ALL 24 layers of the ViT-L/14 tower at the config's batch (128 images,
-    first 4 checked): the bf16 setting must hold the 1e-3 bar; the fp8 setting is MEASURED and printed — every e4m3 rounding
-    of a weight column that meets a channel of magnitude 300 is amplified 300-fold against the other 1022 columns, and 24
-    layers of it add up — and held to a documented, looser bound: a checkpoint with such channels should run the vision
-    tower under set_precision("bf16"). Seeded Gaussian weights without outliers: 5.5e-4 (test_fp8_gpu.py)."""
+    first 4 checked): BOTH settings are held to north_star's 1e-3 (round 6; the fp8 bound was a looser 5e-3 before). Every
+    e4m3 rounding of a weight column that meets a channel of magnitude 300 is amplified 300-fold against the other 1022
+    columns, and 24 layers of it add up: measured 6.7e-4 on these seeded weights, a margin of 1.5 — a checkpoint whose fp8 gap
+    comes out above the bar belongs under set_precision("bf16"), the default. Seeded Gaussian weights without
+    outliers: 5.5e-4 (test_fp8_gpu.py)."""
     import mmiss_amd  # noqa: F401
     from mmiss_amd.encoder import ClipEncoder, ClipShape
     from oracle import clip_oracle as co
@@ -243,7 +244,7 @@ def test_l14_full_depth_outlier_channels_measured():
     enc.close()
     print("outlier channels, ViT-L/14 at FULL depth (24 layers), 128 per call: 1 - cos vs oracle bf16 %.2e, fp8 %.2e" % (d["bf16"], d["fp8"]))
     assert d["bf16"] < COS_TOL, d
-    assert d["fp8"] < 5e-3, d     # (measured, not the parity bar: see the docstring)
+    assert d["fp8"] < COS_TOL, d   # (round 6: held to north_star's tolerance — measured 6.7e-4 on these seeded weights; was 5e-3)
 
 
 def test_drill_set_config0_on_the_gpu(b32_256):

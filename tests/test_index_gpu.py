@@ -335,6 +335,54 @@ def test_save_load_roundtrip(mods, tmp_path, dtype):
         wrong.load(str(p))
 
 
+@pytest.mark.parametrize("dtype", ["f16", "f8"])
+def test_truncated_file_leaves_the_index_as_it_was(mods, tmp_path, dtype):
+    """mmiss_index_load checks the header's row count against the file's length before it overwrites anything: a cut-off
+    file is refused and the index answers exactly as before (fp8: codes and inverse norms still belong together)."""
+    FlatIndex, _, _, ro = mods
+    D = 128
+    c = _corpus(500, D, seed=63)
+    labels = np.arange(500, dtype=np.int64)
+    idx = FlatIndex(D, dtype)
+    idx.add(c, labels)
+    other = FlatIndex(D, dtype)
+    other.add(_corpus(400, D, seed=64), np.arange(400, dtype=np.int64) + 7)
+    p = tmp_path / "shard.mmiss"
+    other.save(str(p))
+    blob = p.read_bytes()
+    q = _corpus(3, D, seed=65)
+    before = idx.query(q, 10)
+    for cut in (len(blob) - 1, len(blob) // 2, 40):
+        (tmp_path / "cut.mmiss").write_bytes(blob[:cut])
+        with pytest.raises(RuntimeError):
+            idx.load(str(tmp_path / "cut.mmiss"))
+        assert idx.count() == 500
+        for x, y in zip(before, idx.query(q, 10)):
+            np.testing.assert_array_equal(x, y)
+        _check(idx, ro, ro.normalize_rows(c, dtype), labels, q, 10)
+    idx.load(str(p))                      # the whole file still loads
+    assert idx.count() == 400
+
+
+def test_removing_every_row_of_an_fp8_index_then_adding_again(mods):
+    """mmiss_index_remove down to zero rows keeps the fp8 invariant (inverse norms zero behind `count`); rows added afterwards
+    answer like a fresh index."""
+    FlatIndex, _, _, ro = mods
+    D = 128
+    c = _corpus(300, D, seed=66)
+    labels = np.arange(300, dtype=np.int64)
+    idx = FlatIndex(D, "f8")
+    idx.add(c, labels)
+    assert idx.remove(labels) == 300 and idx.count() == 0
+    lab, dist, cnt = idx.query(_corpus(2, D, seed=67), 5)
+    assert (lab == -1).all() and (cnt == 0).all()
+    c2 = _corpus(40, D, seed=68)
+    l2 = np.arange(40, dtype=np.int64) + 1000
+    idx.add(c2, l2)
+    _check(idx, ro, ro.normalize_rows(c2, "f8"), l2, _corpus(4, D, seed=69), 10)
+    _check(idx, ro, ro.normalize_rows(c2, "f8"), l2, _corpus(200, D, seed=70), 10)   # the score GEMM's 256-row tile reads behind count
+
+
 def test_blend_matches_oracle_and_reference_formula(mods):
     from oracle import clip_oracle as co
 

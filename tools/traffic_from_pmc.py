@@ -54,6 +54,14 @@ ALGORITHMIC = {  # bytes per launch the kernel must move, 
 }
 
 
+def retrieval_passes():
+    """Query batches per Q leg of tools/retrieval_profile.py (the run the retrieval PMC passes are collected over)."""
+    import os
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "retrieval_profile.py")).read()
+    m = re.search(r"^PASSES\s*=\s*(\d+)", text, flags=re.M)
+    return int(m.group(1)) if m else None
+
+
 def per_kernel(path):
     acc = collections.defaultdict(list)
     with open(path) as f:
@@ -81,6 +89,9 @@ def main(fetch_csv, write_csv, out):
                "write_bytes": round(wb), "traffic_bytes": round(fb + wb),
                # all sampled launches together (classes whose launches differ in size: the score GEMM's sample and filtered pass)
                "traffic_bytes_all_launches": round(2.0 * 1024.0 * sum(fv) + 1024.0 * sum(wv))}
+        if cls in ("score_gemm_f16_strip", "scan_topk_f16") and retrieval_passes():
+            # (only meaningful for passes collected over tools/retrieval_profile.py: bench.py divides the class total by it)
+            ent["batches_if_over_retrieval_profile"] = retrieval_passes()
         if cls in ALGORITHMIC:
             ent["algorithmic_bytes_avg"] = ALGORITHMIC[cls]
             ent["ratio_to_algorithmic"] = round((fb + wb) / ALGORITHMIC[cls], 3)
