@@ -301,12 +301,18 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     if (const int f = mmiss_option("gemm_bm_mlp", 0)) bm_mlp = f;
     auto padded = [&](int bm) { return (int)round_up(M, bm % 1000); };
     const int bm8_qkv = gemm_pick_bm(M, 3 * d), bm8_d = gemm_pick_bm(M, d), bm8_mlp = gemm_pick_bm(M, tw.mlp);
-    // fp8 GEMMs on the persistent 256 x 256 kernel (gemm_fp8_p256.h, round 5) once there is a tile per CU; K % 512 == 0 (ViT-L/14:
-    // every GEMM; ViT-B/32: FC2 only). Option gemm_p256_fp8 = 0 turns it off, n > 1 = minimum tile count.
+    // fp8 GEMMs on the persistent 256 x 256 kernel (gemm_fp8_p256.h, round 5) once there is a tile per CU; K % 256 == 0 (round 6:
+    // every GEMM of ViT-L/14 AND of ViT-B/32, whose K = 768 is three K-tile pairs). Option gemm_p256_fp8 = 0 turns it off,
+    // n > 1 = minimum tile count. The N = 768 GEMMs of ViT-B/32 at 12 800 rows (FC2, out-projection) are 150 tiles — one
+    // short round — and still faster there than on the BM x 128 tile kernel: option gemm_p256_fp8_narrow = the minimum tile
+    // count for such one-round grids (0 = never).
     const int p8_min = mmiss_option("gemm_p256_fp8", 1);
+    const int p8_narrow = mmiss_option("gemm_p256_fp8_narrow", 128);
     auto p8 = [&](int epi, int N, int K) {
         if (p8_min == 0 || !gemm256p8_ok(epi, (int)round_up(M, 256), N, K)) return false;
-        return (int64_t)(round_up(M, 256) / 256) * (N / 256) >= (p8_min > 1 ? p8_min : 256);
+        const int64_t tiles = (int64_t)(round_up(M, 256) / 256) * (N / 256);
+        if (p8_min == 1 && p8_narrow > 0 && tiles < 256 && tiles >= p8_narrow && M >= 6000) return true;   // (measured at 12 800 rows only)
+        return tiles >= (p8_min > 1 ? p8_min : 256);
     };
     auto gemm8_any = [&](int epi, int bm, Gemm8Args g8, int xt = 0) -> int {   // g8.M unset: padded here to the kernel's tile height
         if (xt != 0 || p8(epi, g8.N, g8.K)) { g8.M = (int)round_up(M, 256); return launch_gemm256p8(st, epi, g8, xt); }
@@ -478,9 +484,10 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             else if (use256(3 * d)) MM_TRY(launch_gemm256(st, MMISS_EPI_BIAS_BF16, tw.h.p, L.wqkv.p, ep, padded(256), 3 * d, d));
             else MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_BF16, bm_qkv, tw.h.p, L.wqkv.p, ep, padded(bm_qkv), 3 * d, d));
         }
-        // fp8 tower, long sequences (ViT-L/14): the attention output leaves the kernel as MXFP8 and the out-projection runs
-        // on the fp8 GEMM too (round 4; option fp8_outproj = 0: bf16 ctx + bf16 out-projection as in round 3). Not in the
-        // pruned last layer (its out-projection is a 128-row bf16 GEMM on gathered rows).
+        // fp8 tower: the attention output leaves the kernel as MXFP8 and the out-projection runs on the fp8 GEMM too (round 4:
+        // the long-sequence kernels, ViT-L/14; round 6: the one-pass kernels as well, ViT-B/32's 50 keys; option fp8_outproj = 0:
+        // bf16 ctx + bf16 out-projection as in round 3). Not in the pruned last layer (its out-projection is a 128-row bf16
+        // GEMM on gathered rows).
         const bool last_pruned = prune && l == tw.layers - 1;
         const bool out8 = fp8 && !causal && !last_pruned && resid16 && L.wo8.p && tw.ctx8.p && attention_mx_ok(tw.T, tw.heads) &&
                           mmiss_option("fp8_outproj", 1) != 0;

@@ -480,9 +480,14 @@ __global__ __launch_bounds__(256) void fold_ln_weights_kernel(const uint16_t* __
 
 // One 16-query tile of the one-pass form (T <= 128 keys: all score tiles live in registers). qf = the tile's Q fragments,
 // q = this lane's query row, (b, h) only enter through `orow` = ctx row of q at head h, column 4*fg.
-template <int NKP, bool CAUSAL>
+// MXOUT (round 6: the fp8 tower of ViT-B/32 — 50 keys — feeds its out-projection MXFP8 rows, as attention_long_kernel does for
+// ViT-L/14): instead of bf16 at `orow`, the tile's rows leave as e4m3 at o8row (= ctx8 row of q at head h, column 4*fg) with one
+// E8M0 scale per (query, 32 columns) at srow[mx_scale_offset(2 h + block)] (srow = the row's permuted scale bytes).
+__device__ __forceinline__ float att_max_over_lane_groups(float v);
+template <int NKP, bool CAUSAL, bool MXOUT = false>
 __device__ __forceinline__ void attention_onepass_tile(const char* sK, const char* sV, const bf16x8 (&qf)[2], int q, int T,
-                                                       int fr, int fg, uint16_t* orow) {
+                                                       int fr, int fg, uint16_t* orow, uint8_t* o8row = nullptr, uint8_t* srow = nullptr,
+                                                       int h = 0) {
     f32x4 sacc[2 * NKP];
     float mx = -INFINITY;
 #pragma unroll
@@ -545,7 +550,31 @@ __device__ __forceinline__ void attention_onepass_tile(const char* sK, const cha
         }
     }
     const float inv = 1.0f / l;
-    if (q < T) {
+    if constexpr (MXOUT) {
+        // (every lane takes part in the block maxima — the four lane groups of a query hold its 64 columns; only valid queries store)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float o[2][4];
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[i][r] = oacc[2 * blk + i][r] * inv;
+                    amax = fmaxf(amax, fabsf(o[i][r]));
+                }
+            amax = att_max_over_lane_groups(amax);
+            int e8;
+            float sinv;
+            mx_scale_of(amax, e8, sinv);
+            if (q < T) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    *reinterpret_cast<uint32_t*>(o8row + (2 * blk + i) * 16) = pack_fp8x4(o[i][0] * sinv, o[i][1] * sinv, o[i][2] * sinv, o[i][3] * sinv);
+                if (fg == 0) srow[mx_scale_offset(2 * h + blk)] = (uint8_t)e8;
+            }
+        }
+    } else if (q < T) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             u32x2 pk;
@@ -556,8 +585,9 @@ __device__ __forceinline__ void attention_onepass_tile(const char* sK, const cha
     }
 }
 
-template <int NKP, bool CAUSAL>
-__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx, int T, int H) {
+template <int NKP, bool CAUSAL, bool MXOUT = false>
+__global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx, int T, int H,
+                                                        uint8_t* __restrict__ ctx8 = nullptr, uint8_t* __restrict__ ctxs = nullptr, int ld_s = 0) {
     static_assert(NKP <= 4, "sequences over 128 keys: attention_long_kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKP * 32;
@@ -610,7 +640,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const uint16_t* __restri
                 qf[s] = __builtin_bit_cast(bf16x8, raw);
             }
         }
-        attention_onepass_tile<NKP, CAUSAL>(sK, sV, qf, q, T, fr, fg, ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg);
+        if constexpr (MXOUT) {
+            const size_t row = (size_t)b * T + (q < T ? q : 0);
+            attention_onepass_tile<NKP, CAUSAL, true>(sK, sV, qf, q, T, fr, fg, nullptr, ctx8 + row * dmodel + h * 64 + 4 * fg, ctxs + row * ld_s, h);
+        } else {
+            attention_onepass_tile<NKP, CAUSAL>(sK, sV, qf, q, T, fr, fg, ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg);
+        }
     }
 }
 
@@ -826,9 +861,10 @@ __global__ __launch_bounds__(512) void attention_long_kernel(const uint16_t* __r
 // head h+1 (and its Q fragments) is in flight in registers while head h is computed from LDS (two LDS images, one barrier
 // per head), so a workgroup pays the load latency once instead of HPB times. Same arithmetic, bit-identical output.
 // ------------------------------------------------------------------------------------------------
-template <int NKP, bool CAUSAL, int HPB>
+template <int NKP, bool CAUSAL, int HPB, bool MXOUT = false>
 __global__ __launch_bounds__(256) void attention_heads_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
-                                                              int T, int H) {
+                                                              int T, int H, uint8_t* __restrict__ ctx8 = nullptr,
+                                                              uint8_t* __restrict__ ctxs = nullptr, int ld_s = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TP = NKP * 32;
     constexpr int IMG = TP * (128 + ATT_VSTRIDE);  // one K + V image
@@ -892,6 +928,10 @@ __global__ __launch_bounds__(256) void attention_heads_kernel(const uint16_t* __
         for (int qt = wave; qt < nqt; qt += 4) {
             const int q = qt * 16 + fr;
             if (qt != wave) load_q(h, qt, qf);  // (T > 64: a wave's second tile)
+            if constexpr (MXOUT) {
+                const size_t row = (size_t)b * T + (q < T ? q : 0);
+                attention_onepass_tile<NKP, CAUSAL, true>(sK, sV, qf, q, T, fr, fg, nullptr, ctx8 + row * dmodel + h * 64 + 4 * fg, ctxs + row * ld_s, h);
+            } else
             attention_onepass_tile<NKP, CAUSAL>(sK, sV, qf, q, T, fr, fg, ctx + ((size_t)b * T + q) * dmodel + h * 64 + 4 * fg);
         }
         if (hh + 1 < HPB) {
@@ -1011,13 +1051,15 @@ static int launch_attention_long(hipStream_t st, const void* qkv, void* ctx, uin
     }
 }
 
-// the long-sequence form writing MXFP8: non-causal only (the vision tower), 129..288 keys
-static bool attention_mx_ok(int T, int H) { return T > 128 && T <= 288 && H > 0; }
+// attention writing MXFP8: non-causal only (the vision tower), 1..288 keys (round 6: the one-pass kernels too — ViT-B/32's 50 keys)
+static bool attention_mx_ok(int T, int H) { return T > 0 && T <= 288 && H > 0; }
+static int launch_attention_mx_short(hipStream_t st, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H);
 static int launch_attention_mx(hipStream_t st, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
     if (B <= 0) return MMISS_OK;
     if (!attention_mx_ok(T, H) || !ctx8 || !ctxs || ld_s < mx_scale_row_bytes(H * 64))
-        MM_FAIL(MMISS_ERR_UNSUPPORTED, "attention (MXFP8 output): T=%d (129..288), H=%d", T, H);
+        MM_FAIL(MMISS_ERR_UNSUPPORTED, "attention (MXFP8 output): T=%d (1..288), H=%d", T, H);
     MM_PROF("attention_mx", st, 4.0 * B * H * (double)T * T * 64, (double)B * T * H * 64 * (2 * 3 + 1));
+    if (T <= 128) return launch_attention_mx_short(st, qkv, ctx8, ctxs, ld_s, B, T, H);
     return launch_attention_long<false, true>(st, qkv, nullptr, ctx8, ctxs, ld_s, B, T, H);
 }
 
@@ -1064,6 +1106,50 @@ static int launch_attention_heads_hpb(hipStream_t st, int hpb, const void* qkv, 
         case 3: return launch_attention_heads<NKP, 3>(st, qkv, ctx, B, T, H, causal);
         case 4: return launch_attention_heads<NKP, 4>(st, qkv, ctx, B, T, H, causal);
         default: return launch_attention_heads<NKP, 6>(st, qkv, ctx, B, T, H, causal);
+    }
+}
+
+// T <= 128 with MXFP8 output (non-causal): the same choice between several heads per workgroup and one as launch_attention
+template <int NKP>
+static int launch_attention_mx_nkp(hipStream_t st, int hpb, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
+    auto heads = [&](auto hpb_tag) -> int {
+        constexpr int HPB = decltype(hpb_tag)::value;
+        const int lds = 2 * NKP * 32 * (128 + ATT_VSTRIDE);
+        MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_heads_kernel<NKP, false, HPB, true>), lds));
+        hipLaunchKernelGGL((attention_heads_kernel<NKP, false, HPB, true>), dim3(B * (H / HPB)), dim3(256), lds, st, (const uint16_t*)qkv,
+                           (uint16_t*)nullptr, T, H, ctx8, ctxs, ld_s);
+        MM_HIP(hipGetLastError());
+        return MMISS_OK;
+    };
+    switch (hpb) {
+        case 2: return heads(std::integral_constant<int, 2>{});
+        case 3: return heads(std::integral_constant<int, 3>{});
+        case 4: return heads(std::integral_constant<int, 4>{});
+        case 6: return heads(std::integral_constant<int, 6>{});
+    }
+    const int lds = NKP * 32 * (128 + ATT_VSTRIDE);
+    const int rounds = ((T + 15) / 16 + 3) / 4;
+    int qs = 256 / (B * H);
+    qs = qs < 1 ? 1 : (qs > rounds ? rounds : qs);
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<NKP, false, true>), lds));
+    hipLaunchKernelGGL((attention_kernel<NKP, false, true>), dim3(B * H, qs), dim3(256), lds, st, (const uint16_t*)qkv, (uint16_t*)nullptr, T, H,
+                       ctx8, ctxs, ld_s);
+    MM_HIP(hipGetLastError());
+    return MMISS_OK;
+}
+static int launch_attention_mx_short(hipStream_t st, const void* qkv, uint8_t* ctx8, uint8_t* ctxs, int ld_s, int B, int T, int H) {
+    int hpb = mmiss_option("att_hpb", 0);
+    if (hpb == 0) {
+        hpb = 1;
+        for (int c : {4, 6, 3, 2})
+            if (H % c == 0 && (int64_t)B * (H / c) >= 512) { hpb = c; break; }
+    }
+    if (!((hpb == 2 || hpb == 3 || hpb == 4 || hpb == 6) && H % hpb == 0)) hpb = 1;
+    switch ((T + 31) / 32) {
+        case 1: return launch_attention_mx_nkp<1>(st, hpb, qkv, ctx8, ctxs, ld_s, B, T, H);
+        case 2: return launch_attention_mx_nkp<2>(st, hpb, qkv, ctx8, ctxs, ld_s, B, T, H);
+        case 3: return launch_attention_mx_nkp<3>(st, hpb, qkv, ctx8, ctxs, ld_s, B, T, H);
+        default: return launch_attention_mx_nkp<4>(st, hpb, qkv, ctx8, ctxs, ld_s, B, T, H);
     }
 }
 

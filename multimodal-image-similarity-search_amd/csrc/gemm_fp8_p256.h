@@ -31,7 +31,18 @@
 //     GEMV-shaped job), the eight partial sums added in wave order through LDS, the epilogue by wave 0. ~4 us instead of
 //     13-44. (The partial sums make these rows differ from gemm8_kernel's in the last bits of the f32 sums; the tile rows
 //     stay bit-identical.)
-// K % 512 == 0 (an even number of pairs per tile: the scale pieces of a group need two), M, N % 256 == 0.
+//   * K % 256 == 0 (round 6; was K % 512). A tile is K / 256 K-tile PAIRS; the scale ring works in 512-k groups of two pairs,
+//     one piece per pair. K = 768 — every GEMM input of ViT-B/32, the metric's own model — is three pairs: a full group and a
+//     HALF group (K-tiles 4, 5 = bytes 0, 1 of the row's second 16 scale bytes). Template parameter ODD = such a tile. The
+//     half group's one pair must bring BOTH slots of the next tile's group 0, so an ODD kernel issues two pieces at the head
+//     of EVERY pair — both slots of the group that follows the pair's own; the second pair of a full group repeats the first
+//     one's pieces (the same bytes to the same place: 512 B per wave and tile) — which keeps the piece count per pair a
+//     constant (every counted wait an immediate: the four waits behind the pieces allow two more operations in flight, the
+//     fifth retires both) AND the loop's control flow the K % 512 kernel's: a third form of the pair for the half group alone
+//     cost the register allocator 390 spilled registers. The K-tile counter that picks a lane's scale byte restarts at every
+//     tile. Everything else — the ring's parity per group, the epilogues, the ragged pass — is the K % 512 kernel's; the
+//     ODD = 0 instantiations are unchanged.
+// K >= 512, K % 256 == 0, M, N % 256 == 0.
 #pragma once
 #include <type_traits>
 #include "gemm_fp8.h"
@@ -79,11 +90,12 @@ __device__ __forceinline__ f32x4 q256_halves_to_f32x4(u32x2 h) {   // four f16 -
                  (float)__builtin_bit_cast(_Float16, (uint16_t)(w1 & 0xffffu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(w1 >> 16))};
 }
 
-template <int EPI, int XT = 0>
+template <int EPI, int XT = 0, int ODD = 0>
 __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(EPI == MMISS_EPI8_BIAS_BF16 || EPI == MMISS_EPI8_QGELU_MXFP8 || EPI == MMISS_EPI8_BIAS_RESID_BF16, "epilogue");
     static_assert(XT == 0 || (XT == 1 && EPI != MMISS_EPI8_BIAS_RESID_BF16) || (XT == 2 && EPI == MMISS_EPI8_BIAS_RESID_BF16), "extension");
+    static_assert(ODD == 0 || XT == 0, "the extensions exist for K = 1024 only");
     constexpr bool FOLD = XT == 1, MXQ = XT == 2;
     // vector-memory operations of a wave between two tiles' K streams: the epilogue's stores (16; MXQ: 5 x 8 + the statistics) + the
     // pieces of stage_x (bias / wscale; FOLD: + c + the raw statistics)
@@ -102,9 +114,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     const int fr = lane & 15, fg = lane >> 4;
     const int M = g.M, N = g.N, K = g.K;
     const int nbm = (M >> 8) - (g.ragged > 0 ? 1 : 0), nbn = N >> 8;   // (a ragged last row block is not a tile)
-    const int nt = K >> 7;          // K-tiles per tile, a multiple of 4
-    const int npair = nt >> 1;      // even
-    const int ngrp = nt >> 2;       // 512-k scale groups per tile
+    const int nt = K >> 7;          // K-tiles per tile, even (ODD = 0: a multiple of 4)
+    const int npair = nt >> 1;      // ODD = npair & 1
+    const int ngrp = (nt + 3) >> 2; // 512-k scale groups per tile (ODD: the last one is a half group of one pair)
     __builtin_assume(npair >= 2);   // (K >= 512: no zero-trip copies of the K loop, whose accumulator joins cost registers)
 #ifdef MMISS_EXPERIMENTS
     // timing experiment (profiles/gemm_fp8_p256_r05.txt): do the workgroups' epilogues cost more because all 256 run them at once?
@@ -451,7 +463,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
 #define Q256_WADJ 0
 #endif
 // counted wait: 10 younger slot pieces stay in flight; POST: + the previous tile's epilogue operations; XS: + the pair's scale piece
-#define Q256_WAIT(POST, XS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 - Q256_WADJ + ((POST) ? EX : 0) + ((XS) ? 1 : 0)) : "memory")
+// (ODD: two scale pieces per pair)
+#define Q256_WAIT(POST, XS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 - Q256_WADJ + ((POST) ? EX : 0) + ((XS) ? 1 + ODD : 0)) : "memory")
 #define Q256_BARRIER()                       \
     {                                        \
         __builtin_amdgcn_sched_barrier(0);   \
@@ -509,7 +522,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     } else {                                                                                                \
         oA2 += 128; oW2 += 128;                                                                             \
     }                                                                                                       \
-    sc_off = ((++kt_cur) & 3) == 0 ? ((sc_off & 4096) ^ 4096) : sc_off + 1;
+    ++kt_cur;                                                                                               \
+    if constexpr (ODD) { if (kt_cur == nt) kt_cur = 0; } /* (a half group ends the tile: the count restarts with the next) */ \
+    sc_off = (kt_cur & 3) == 0 ? ((sc_off & 4096) ^ 4096) : sc_off + 1;
 // the scale piece at the head of a pair: A slot `pc_mq` of scale group `pc_g` of tile position `pc_o` into the ring parity of
 // that group; then the cursor moves on (the tile's last group is followed by group 0 of the workgroup's next tile, whose
 // rows come from the tile list; past the last tile it re-reads the last one)
@@ -530,6 +545,28 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
             }                                                                                               \
         }                                                                                                   \
     }
+
+// ODD: both slots of the cursor's group at the head of every pair; the cursor moves on behind the second pair of a full group and
+// behind the half group's only pair (kp = this pair's index in its tile)
+#define Q256_SCALE_PIECE2(kp)                                                                                \
+    {                                                                                                       \
+        Q256_BLDS4(srdS, s_vo, pc_so, smem + Q256_RING + pc_par + wave * 256);                              \
+        Q256_BLDS4(srdS, s_vo, pc_so + 64 * g.ld_as, smem + Q256_RING + pc_par + 2048 + wave * 256);        \
+        if (((kp) & 1) || (kp) == npair - 1) {                                                              \
+            pc_par ^= 4096;                                                                                 \
+            if (++pc_g == ngrp) {                                                                           \
+                pc_g = 0;                                                                                   \
+                if (pc_o + 1 < mine) ++pc_o;                                                                \
+                int bm_, bn_, hf_;                                                                          \
+                tile_of(pc_o, bm_, bn_, hf_);                                                               \
+                pc_so = (bm_ * 256 + (hf_ == 2 ? 64 : 0)) * g.ld_as;                                        \
+            } else {                                                                                        \
+                pc_so += 16;                                                                                \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+#define Q256_PAIR_PIECES(kp) \
+    if constexpr (ODD) { Q256_SCALE_PIECE2(kp); } else { Q256_SCALE_PIECE(); }
 
     // ---- stream state
     int cbm, cbn, chalf;
@@ -799,7 +836,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     // ---- whole tiles. Pair kp of a tile: scale piece, K-tile 2 kp out of buffer 0, K-tile 2 kp + 1 out of buffer 1.
     for (int ti = 0; ti < nfull; ++ti) {
         for (int kp = 0; kp < npair; ++kp) {
-            Q256_SCALE_PIECE();
+            Q256_PAIR_PIECES(kp);
             if (kp == 0 && ti > 0) {
                 Q256_KTILE(0, true, true, true, true, true, true, false);
                 Q256_KTILE(1, true, false, false, true, false, false, false);
@@ -822,7 +859,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
     // ---- the half tile of the last round, if this workgroup has one (always behind at least one whole tile: POST waits)
     if (nhalf) {
         for (int kp = 0; kp < npair; ++kp) {
-            Q256_SCALE_PIECE();
+            Q256_PAIR_PIECES(kp);
             if (kp == 0) {
                 Q256_KTILE(0, true, true, true, true, true, true, true);
                 Q256_KTILE(1, true, false, false, true, false, false, true);
@@ -857,22 +894,24 @@ __global__ __launch_bounds__(512, 2) void gemm256p8_kernel(Gemm8Args g) {
 #undef Q256_WADJ
 #undef Q256_ADVANCE
 #undef Q256_SCALE_PIECE
+#undef Q256_SCALE_PIECE2
+#undef Q256_PAIR_PIECES
 
 // can this GEMM run on the persistent fp8 kernel?
 static inline bool gemm256p8_ok(int epi, int M, int N, int K) {
-    if (M <= 0 || (M % 256) || N <= 0 || (N % 256) || K < 512 || (K % 512)) return false;
+    if (M <= 0 || (M % 256) || N <= 0 || (N % 256) || K < 512 || (K % 256)) return false;
     if ((int64_t)(M / 256) * (N / 256) > 48 * 256 || M / 256 > 0xffff) return false;  // (tile table: 64 entries per workgroup)
     if ((int64_t)M * N * 2 >= (1LL << 31) || (int64_t)M * K >= (1LL << 31) || (int64_t)N * K >= (1LL << 31)) return false;  // (32-bit buffer offsets)
     return epi == MMISS_EPI8_BIAS_BF16 || epi == MMISS_EPI8_QGELU_MXFP8 || epi == MMISS_EPI8_BIAS_RESID_BF16;
 }
 
-template <int EPI, int XT>
+template <int EPI, int XT, int ODD = 0>
 static int launch_gemm256p8_inst(hipStream_t st, const Gemm8Args& g) {
     const int T = (g.M / 256 - (g.ragged > 0 ? 1 : 0)) * (g.N / 256);
     const int grid = T >= 256 ? 256 : T;
     constexpr int LDS = XT == 1 ? Q256_LDS_FOLD : Q256_LDS;
-    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p8_kernel<EPI, XT>), LDS));
-    hipLaunchKernelGGL((gemm256p8_kernel<EPI, XT>), dim3(grid), dim3(512), LDS, st, g);
+    MM_TRY(mmiss_ensure_dyn_lds(reinterpret_cast<const void*>(&gemm256p8_kernel<EPI, XT, ODD>), LDS));
+    hipLaunchKernelGGL((gemm256p8_kernel<EPI, XT, ODD>), dim3(grid), dim3(512), LDS, st, g);
     MM_HIP(hipGetLastError());
     return MMISS_OK;
 }
@@ -881,6 +920,7 @@ static int launch_gemm256p8_inst(hipStream_t st, const Gemm8Args& g) {
 // also leaves the new rows as MXFP8 with their statistics (N = 1024; no half tiles: the tile count must not end in a short round)
 static inline bool gemm256p8_xt_ok(int epi, int xt, const Gemm8Args& g) {
     if (xt == 0) return true;
+    if (g.K % 512) return false;   // (the extensions: whole 512-k groups only)
     if (xt == 1)
         return (epi == MMISS_EPI8_BIAS_BF16 || epi == MMISS_EPI8_QGELU_MXFP8) && g.K == 1024 && g.c16 && g.ln_stats && g.x16;
     if (xt != 2 || epi != MMISS_EPI8_BIAS_RESID_BF16 || g.N != 1024 || !g.q_out || !g.q_scale || !g.stats_out ||
@@ -917,6 +957,11 @@ static int launch_gemm256p8(hipStream_t st, int epi, Gemm8Args g, int xt = 0) {
         return launch_gemm256p8_inst<MMISS_EPI8_QGELU_MXFP8, 1>(st, g);
     }
     if (xt == 2) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_RESID_BF16, 2>(st, g);
+    if (g.K % 512) {   // an odd number of K-tile pairs per tile (K = 768: ViT-B/32)
+        if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_BF16, 0, 1>(st, g);
+        if (epi == MMISS_EPI8_QGELU_MXFP8) return launch_gemm256p8_inst<MMISS_EPI8_QGELU_MXFP8, 0, 1>(st, g);
+        return launch_gemm256p8_inst<MMISS_EPI8_BIAS_RESID_BF16, 0, 1>(st, g);
+    }
     if (epi == MMISS_EPI8_BIAS_BF16) return launch_gemm256p8_inst<MMISS_EPI8_BIAS_BF16, 0>(st, g);
     if (epi == MMISS_EPI8_QGELU_MXFP8) return launch_gemm256p8_inst<MMISS_EPI8_QGELU_MXFP8, 0>(st, g);
     return launch_gemm256p8_inst<MMISS_EPI8_BIAS_RESID_BF16, 0>(st, g);

@@ -121,7 +121,10 @@ def test_layernorm_mxfp8_from_bf16_rows(env, d):
     assert (np.abs(back - y) <= gmax * 2.0 ** -4 * 1.01 + 1e-6).all()
 
 
-@pytest.mark.parametrize("B,T,H", [(3, 257, 16), (2, 200, 4), (33, 257, 16), (43, 257, 12)])   # (the last two: attention_stream_kernel, 2-3 pairs per workgroup)
+@pytest.mark.parametrize("B,T,H", [(3, 257, 16), (2, 200, 4), (33, 257, 16), (43, 257, 12),   # (the last two: attention_stream_kernel, 2-3 pairs per workgroup)
+                                   # round 6: the one-pass kernels (T <= 128) write MXFP8 too — ViT-B/32's 50 keys at bs 256 (four heads per
+                                   # workgroup), a small batch (one head per workgroup, query tiles split), 77 and 128 keys, a lone query
+                                   (256, 50, 12), (3, 50, 12), (40, 77, 8), (2, 128, 2), (1, 1, 2)])
 def test_attention_with_mxfp8_output(env, B, T, H):
     """The fp8 vision tower's attention writes its output as MXFP8 (the out-projection's A operand on the fp8 GEMM): the
     dequantised bytes must equal the bf16-output kernel's rows up to the e4m3 rounding of a block — 2^-4 of the block's
@@ -148,7 +151,12 @@ def test_attention_with_mxfp8_output(env, B, T, H):
                                           (3, 128, 256, 256, 512),
                                           # bm = 256: the persistent 256 x 256 kernel of round 5 (gemm_fp8_p256.h), K % 512 == 0
                                           (0, 256, 512, 768, 512), (1, 256, 768, 512, 1024), (3, 256, 256, 1024, 2048),
-                                          (0, 256, 256, 256, 4096)])
+                                          (0, 256, 256, 256, 4096),
+                                          # round 6: K % 256 == 0 — an odd number of K-tile pairs per tile (K = 768: ViT-B/32): a half scale group
+                                          # at the tile's end, two scale pieces per pair; several tiles per workgroup (768 x 2304 is 27 tiles...
+                                          (0, 256, 768, 2304, 768), (1, 256, 512, 1024, 768), (3, 256, 512, 768, 768), (0, 256, 256, 512, 1280),
+                                          # ... and more tiles than CUs: 77 x 4 = 308 whole tiles, a last round in halves)
+                                          (3, 256, 19712, 1024, 768)])
 def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
     """A8 / W8 random e4m3 bytes, activation block scales spread over 2^-6 .. 2^5: the MFMA result must equal the float64
     product of the DEQUANTISED operands up to fp32 accumulation — this pins the operand layout, the lane <-> k-block <->
@@ -214,14 +222,20 @@ def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
 
 @pytest.mark.parametrize("epi,M,mv,N,K", [(0, 33024, 32896, 3072, 1024), (1, 33024, 32896, 4096, 1024), (3, 33024, 32896, 1024, 1024),
                                           (3, 33024, 32896, 1024, 4096), (0, 12800, 12800, 2304, 3072), (1, 2048, 2000, 512, 512),
-                                          (3, 16640, 16600, 768, 1536)])
+                                          (3, 16640, 16600, 768, 1536),
+                                          # round 6: ViT-B/32 at batch 256 (12 800 rows), K = 768 = three K-tile pairs per tile: QKV (450 tiles),
+                                          # FC1 -> MXFP8 (600 tiles: two rounds + halves), out-projection (150 tiles: one short round), FC2
+                                          # (K = 3072); a ragged last row block with five pairs per tile
+                                          (0, 12800, 12800, 2304, 768), (1, 12800, 12800, 3072, 768), (3, 12800, 12800, 768, 768),
+                                          (3, 12800, 12800, 768, 3072), (1, 2048, 1900, 512, 1280)])
 def test_persistent_fp8_gemm_equals_the_tile_kernel_bit_for_bit(env, epi, M, mv, N, K):
     """gemm256p8_kernel (round 5: one workgroup per CU, ONE K-tile stream over its tiles, staggered wave halves, the block
     scales through an LDS ring) against gemm8_kernel (BM x 128 tiles) on the same bytes: both sum a row's K-tiles in ascending
     order on the same instruction and apply the same epilogue arithmetic, so every output byte must be equal — at BASELINE
     configs[4]'s own shapes (ViT-L/14 at batch 128: 32 896 valid of 33 024 padded rows; QKV, FC1 -> MXFP8, out-projection and
-    FC2 on the bf16 residual stream: 2-8 whole tiles per workgroup plus the half tiles of the last round), ViT-B/32's FC2,
-    and two small grids (fewer tiles than CUs; a ragged last row block). Rows >= m_valid are not compared."""
+    FC2 on the bf16 residual stream: 2-8 whole tiles per workgroup plus the half tiles of the last round), ViT-B/32's four
+    GEMMs at batch 256 (round 6: K = 768, an odd number of K-tile pairs per tile), and small grids (fewer tiles than CUs; a
+    ragged last row block). Rows >= m_valid are not compared."""
     torch, _lib, lib, fo = env
     g = torch.Generator(device="cuda").manual_seed(1000 * epi + K + N)
     tab = fo.e4m3_table()

@@ -102,6 +102,73 @@ def test_b32_bs256_outlier_hidden_channels(b32_256):
     enc.close()
 
 
+def test_b32_bs256_fp8_setting_on_the_persistent_kernels_holds_the_bar(b32_256):
+    """Round 6: ViT-B/32 — the metric's own model — under set_precision("fp8") at batch 256: QKV, FC1 (K = 768:
+    three K-tile pairs per tile), FC2 and the out-projection (A = the 50-key attention's MXFP8 output) ALL run on the persistent
+    block-scaled fp8 GEMM. 1 - cos against the fp32 oracle (24 images incl. three with a large mean / std ratio), against the
+    transformers golden vectors (four images inside a batch of 256) and against the bf16 path, all at north_star's 1e-3; the
+    setting stays an opt-in and `value` stays the bf16 step (include/mmiss.h)."""
+    enc, small, W, co = b32_256
+    s = co.VIT_B32
+    rng = np.random.Generator(np.random.Philox(1234))
+    px = rng.standard_normal((256, 3, 224, 224), dtype=np.float32)
+    px[5] = px[5] * 0.05 + 4.0
+    px[77] = px[77] * 3.0 - 2.5
+    px[200] = np.abs(px[200]) * 2.0
+    g = np.load(os.path.join(G, "clip_b32.npz"))
+    gpx = np.random.Generator(np.random.Philox(int(g["pixel_seed"]))).standard_normal((4, 3, 224, 224), dtype=np.float32)
+    big = np.random.Generator(np.random.Philox(9)).standard_normal((256, 3, 224, 224), dtype=np.float32)
+    big[[0, 100, 200, 255]] = gpx
+    ref16 = enc.encode_image(px)
+    enc.set_precision("fp8")
+    try:
+        out, kern = _kernels_of(lambda: enc.encode_image(px))
+        gold = enc.encode_image(big)[[0, 100, 200, 255]]
+        again = enc.encode_image(px)
+    finally:
+        enc.set_precision("bf16")
+    # 12 QKV, 11 FC1 + 11 FC2 + 11 out-projections (the pruned last layer's three run on the 128-row bf16 kernels), 11 attentions -> MXFP8
+    assert kern.get("gemm_fp8_bias_p256", 0) == 12 and kern.get("gemm_fp8_qgelu_mx_p256", 0) == 11, kern
+    assert kern.get("gemm_fp8_bias_resid16_p256", 0) == 22 and kern.get("attention_mx", 0) == 11 and kern.get("attention", 0) == 1, kern
+    assert not any(k.startswith("gemm_fp8") and not k.endswith("_p256") for k in kern), kern
+    sub = np.concatenate([[5, 77, 200], np.arange(0, 256, 13)])[:24]
+    d = 1 - _cos(out[sub], co.embed_images(px[sub], W, s))
+    d16 = 1 - _cos(out, ref16)
+    dg = 1 - _cos(gold, g["image"])
+    print("ViT-B/32 bs 256, fp8 setting: 1 - cos vs fp32 oracle %.2e, vs the bf16 path %.2e, vs the transformers golden %.2e" % (d.max(), d16.max(), dg.max()))
+    assert d.max() < COS_TOL, d
+    assert dg.max() < COS_TOL, dg
+    assert d16.max() < COS_TOL
+    assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-5
+    np.testing.assert_array_equal(out, again)  # deterministic
+
+
+def test_b32_bs256_fp8_setting_with_outlier_hidden_channels(b32_256):
+    """The +300 / -180 residual channels of test_b32_bs256_outlier_hidden_channels under set_precision("fp8"): measured and
+    printed; held to north_star's 1e-3 like every default setting — if a checkpoint does not hold it, fp8 stays off for it
+    (the default is bf16; include/mmiss.h says so)."""
+    from mmiss_amd.encoder import ClipEncoder, ClipShape
+
+    _, _, W0, co = b32_256
+    s = co.VIT_B32
+    W = dict(W0)
+    pos = W["vision_model.embeddings.position_embedding.weight"].copy()
+    pos[:, 31] += 300.0
+    pos[:, 500] -= 180.0
+    W["vision_model.embeddings.position_embedding.weight"] = pos
+    enc = ClipEncoder(ClipShape.from_any(s), max_batch_image=256, max_batch_text=8, precision="fp8")
+    enc.load_state_dict(W)
+    rng = np.random.Generator(np.random.Philox(4321))
+    px = rng.standard_normal((256, 3, 224, 224), dtype=np.float32)
+    out, kern = _kernels_of(lambda: enc.encode_image(px))
+    assert kern.get("gemm_fp8_bias_p256", 0) == 12, kern
+    sub = np.arange(3, 256, 32)
+    d = 1 - _cos(out[sub], co.embed_images(px[sub], W, s))
+    print("ViT-B/32 bs 256, fp8 setting, outlier channels +300 / -180: 1 - cos vs fp32 oracle %.2e" % d.max())
+    assert d.max() < COS_TOL, d
+    enc.close()
+
+
 def test_b32_text_tower_256x77_default_path(b32_256):
     """configs[2] shapes: 256 prompts x 77 tokens = 19712 rows -> folded path, causal attention, first-EOS pooling."""
     enc, small, W, co = b32_256
