@@ -558,11 +558,15 @@ __global__ __launch_bounds__(256) void layernorm_mxfp8_kernel(const void* __rest
 // registers, all four rows' loads issued before the first is used. A 32-column block = 4 lanes: two xor-shuffles.
 // Same statistics, same y, same scales and bytes as layernorm_mxfp8_kernel<true> (the sums run in a different lane order:
 // the last bit of mean / rstd may differ).
-template <int NS>
+// D = 768 (round 6: ViT-B/32's fp8 tower, 23 launches per bs-256 encode on the one-lane-four-columns form before): NS = 2 with the
+// second step's lanes 32..63 idle (columns 768..1023 do not exist: zeros into the sums, nothing stored) — a quarter of the lane
+// slots of a memory-bound kernel; a 32-column block never straddles the boundary (lane 32 = column 768).
+template <int NS, int D = NS * 512>
 __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, uint8_t* __restrict__ out,
                                                                      uint8_t* __restrict__ out_scale, int M, int ld_os, float eps) {
-    constexpr int D = NS * 512, RW = 4;
+    constexpr int RW = 4;
+    static_assert(D <= NS * 512 && D > (NS - 1) * 512 && D % 32 == 0, "columns");
     const int lane = threadIdx.x & 63;
     const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
     if (r0 >= M) return;
@@ -570,8 +574,10 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int c = i * 512 + lane * 8;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c), g1 = *reinterpret_cast<const f32x4*>(gamma + c + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c), b1 = *reinterpret_cast<const f32x4*>(beta + c + 4);
+        const bool live = (i + 1) * 512 <= D || c < D;
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 g0 = live ? *reinterpret_cast<const f32x4*>(gamma + c) : z, g1 = live ? *reinterpret_cast<const f32x4*>(gamma + c + 4) : z;
+        const f32x4 b0 = live ? *reinterpret_cast<const f32x4*>(beta + c) : z, b1 = live ? *reinterpret_cast<const f32x4*>(beta + c + 4) : z;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gm[i][e] = g0[e]; gm[i][4 + e] = g1[e]; bb[i][e] = b0[e]; bb[i][4 + e] = b1[e]; }
     }
@@ -580,7 +586,10 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
     for (int j = 0; j < RW; ++j) {
         const int r = r0 + j < M ? r0 + j : M - 1;
 #pragma unroll
-        for (int i = 0; i < NS; ++i) raw[j][i] = *reinterpret_cast<const u32x4*>(x + (size_t)r * D + i * 512 + lane * 8);
+        for (int i = 0; i < NS; ++i) {
+            const bool live = (i + 1) * 512 <= D || i * 512 + lane * 8 < D;
+            raw[j][i] = live ? *reinterpret_cast<const u32x4*>(x + (size_t)r * D + i * 512 + lane * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
     }
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
@@ -599,12 +608,14 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
         const float mean = wave_sum(s) * (1.0f / (float)D);
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < NS; ++i)
+        for (int i = 0; i < NS; ++i) {
+            const bool live = (i + 1) * 512 <= D || i * 512 + lane * 8 < D;   // (a column that does not exist adds nothing to the variance)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float t = v[i][e] - mean;
-                q += t * t;
+                q += live ? t * t : 0.f;
             }
+        }
         const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -620,8 +631,8 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
             int e8;
             float inv;
             mx_scale_of(amax, e8, inv);
-            if (r < M) {
-                const int c = i * 512 + lane * 8;
+            const int c = i * 512 + lane * 8;
+            if (r < M && ((i + 1) * 512 <= D || c < D)) {
                 u32x2 pk;
                 pk[0] = pack_fp8x4(y[0] * inv, y[1] * inv, y[2] * inv, y[3] * inv);
                 pk[1] = pack_fp8x4(y[4] * inv, y[5] * inv, y[6] * inv, y[7] * inv);
@@ -717,7 +728,7 @@ static int launch_layernorm_mxfp8(hipStream_t st, const void* x, bool x_bf16, co
                                   uint8_t* out_scale, int M, int d, float eps) {
     if (d > 1024 || (d % 32)) MM_FAIL(MMISS_ERR_UNSUPPORTED, "layernorm_mxfp8: d=%d (need d <= 1024, d %% 32 == 0)", d);
     MM_PROF(x_bf16 ? "layernorm16_mxfp8" : "layernorm_mxfp8", st, 8.0 * M * d, (double)M * d * (x_bf16 ? 3 : 5));
-    if (x_bf16 && (d == 512 || d == 1024) && mmiss_option("ln_mxfp8_wide", 1) != 0) {
+    if (x_bf16 && (d == 512 || d == 768 || d == 1024) && mmiss_option("ln_mxfp8_wide", 1) != 0) {
         const int grid = (M + 15) / 16;
         if (d == 1024 && mmiss_option("ln_mxfp8_wide", 1) == 1)
             hipLaunchKernelGGL(layernorm16_mxfp8_1024_kernel<4>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
@@ -730,6 +741,9 @@ static int launch_layernorm_mxfp8(hipStream_t st, const void* x, bool x_bf16, co
                                beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
         else if (d == 1024)   // (option ln_mxfp8_wide = 2: the 8-columns-per-lane form, A/B)
             hipLaunchKernelGGL(layernorm16_mxfp8_wide_kernel<2>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
+                               beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
+        else if (d == 768)
+            hipLaunchKernelGGL((layernorm16_mxfp8_wide_kernel<2, 768>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,
                                beta, out, out_scale, M, mx_scale_row_bytes(d), eps);
         else
             hipLaunchKernelGGL(layernorm16_mxfp8_wide_kernel<1>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint16_t*>(x), gamma,

@@ -384,7 +384,7 @@ def test_attention_257_keys_last_query_every_key_counts(env, B, H):
     torch.cuda.synchronize()
     ref, bound = _attn_ref(torch, qkv, B, T, H, False, with_bound=True)
     last = torch.arange(B, device="cuda") * T + (T - 1)
-    assert bound[last].max().item() < 1e-2                                   # (2.5e-3 + 2e-3 + 4e-3 here)
+    assert bound[last].max().item() < 2e-2                                   # (2.5e-3 + 2^-8 |out| <= 8e-3 + 4e-3 here; one lost key: 3.1e-2)
     _assert_attention_close(torch, ctx[last], ref[last], bound[last])
     _assert_attention_close(torch, ctx, ref, bound)
     # the power of the test: the same reference with ONE key removed (the last, the first, one in the middle) is outside the bound
