@@ -303,11 +303,13 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     const int bm8_qkv = gemm_pick_bm(M, 3 * d), bm8_d = gemm_pick_bm(M, d), bm8_mlp = gemm_pick_bm(M, tw.mlp);
     // fp8 GEMMs on the persistent 256 x 256 kernel (gemm_fp8_p256.h, round 5) once there is a tile per CU; K % 256 == 0 (round 6:
     // every GEMM of ViT-L/14 AND of ViT-B/32, whose K = 768 is three K-tile pairs). Option gemm_p256_fp8 = 0 turns it off,
-    // n > 1 = minimum tile count. The N = 768 GEMMs of ViT-B/32 at 12 800 rows (FC2, out-projection) are 150 tiles — one
-    // short round — and still faster there than on the BM x 128 tile kernel: option gemm_p256_fp8_narrow = the minimum tile
-    // count for such one-round grids (0 = never).
+    // n > 1 = minimum tile count. The N = 768 GEMMs of ViT-B/32 at 12 800 rows (FC2, out-projection) are 150 tiles of 256 x 256
+    // — one round on 150 of the 256 CUs — and measure SLOWER there than on the BM x 128 tile kernel, whose 600+ smaller tiles
+    // fill the chip (tools/b32_kernel_table.py, profiles/b32_fp8_r06.txt: 34.1 vs 30.7 us per launch on average, the encode
+    // 113.4 vs 117.7 k images/s): they stay on gemm8_kernel. Option gemm_p256_fp8_narrow = the minimum tile count from which
+    // such one-round grids take the persistent kernel anyway (0 = never, the default).
     const int p8_min = mmiss_option("gemm_p256_fp8", 1);
-    const int p8_narrow = mmiss_option("gemm_p256_fp8_narrow", 128);
+    const int p8_narrow = mmiss_option("gemm_p256_fp8_narrow", 0);
     auto p8 = [&](int epi, int N, int K) {
         if (p8_min == 0 || !gemm256p8_ok(epi, (int)round_up(M, 256), N, K)) return false;
         const int64_t tiles = (int64_t)(round_up(M, 256) / 256) * (N / 256);
@@ -394,6 +396,12 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // partial statistics per 16 columns, the skinny QKV / FC1 GEMMs apply (mean, rstd) in their epilogue. 24 of the ~99
     // launches of a ViT-B/32 request disappear. Option skinny_fold = 0 keeps the LayerNorm kernels.
     const bool sfold = plain && !fp8 && skinny_fold_ok(tw, M);
+    // ... and every skinny launch touches the lines of the NEXT skinny launch's weights (GemmEpi::pf; round 6, VERDICT r5 next #8;
+    // option skinny_prefetch, measured in profiles/single_request_r06.txt)
+    const bool spf = sfold && mmiss_option("skinny_prefetch", 0) != 0;
+    auto set_pf = [&](GemmEpi& e_, const DevBuf& w, int N_, int K_) {
+        if (spf && w.p) { e_.pf = w.p; e_.pf_blocks = N_ / 16; e_.pf_block_bytes = 16 * K_ * 2; }
+    };
     const int parts = d / 64;
     const bool have_embed_stats16 = tw.embed_stats16;   // (the one-request embedding stage already wrote xb + the 16-column statistics)
     tw.embed_stats16 = false;
@@ -474,6 +482,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         } else if (sfold) {
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = d / 16; ep.ln_eps = eps; ep.stats16 = 1;
+            set_pf(ep, L.wo, d, d);   // (the attention kernel in between reads no weights)
             MM_TRY(launch_gemm_skinny_fold(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, M, 3 * d, d));
         } else {
             if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, M, d, eps));
@@ -533,6 +542,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             if (p160(d, d)) MM_TRY(launch_gemm160p(st, tw.ctx.p, L.wo.p, ep, padded(160), d, d));
             else MM_TRY(launch_gemm_resid16(st, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         } else {
+            if (sfold) set_pf(ep, L.w1_f, tw.mlp, d);
             MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         }
         ep = GemmEpi{};
@@ -574,6 +584,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         } else if (sfold) {
             ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = d / 16; ep.ln_eps = eps; ep.stats16 = 1;
+            set_pf(ep, L.w2, d, tw.mlp);
             MM_TRY(launch_gemm_skinny_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, M, tw.mlp, d));
         } else {
             if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, M, d, eps));
@@ -595,6 +606,7 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             if (p160(d, tw.mlp)) MM_TRY(launch_gemm160p(st, tw.u.p, L.w2.p, ep, padded(160), d, tw.mlp));
             else MM_TRY(launch_gemm_resid16(st, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         } else {
+            if (sfold && l + 1 < tw.layers) set_pf(ep, tw.L[l + 1].wqkv_f, 3 * d, d);
             MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         }
         MM_TRY(tap(l + 1));

@@ -104,8 +104,8 @@ def test_b32_bs256_outlier_hidden_channels(b32_256):
 
 def test_b32_bs256_fp8_setting_on_the_persistent_kernels_holds_the_bar(b32_256):
     """Round 6: ViT-B/32 — the metric's own model — under set_precision("fp8") at batch 256: QKV, FC1 (K = 768:
-    three K-tile pairs per tile), FC2 and the out-projection (A = the 50-key attention's MXFP8 output) ALL run on the persistent
-    block-scaled fp8 GEMM. 1 - cos against the fp32 oracle (24 images incl. three with a large mean / std ratio), against the
+    three K-tile pairs per tile) run on the persistent block-scaled fp8 GEMM, FC2 and the out-projection (A = the 50-key
+    attention's MXFP8 output) on the fp8 tile kernel. 1 - cos against the fp32 oracle (24 images incl. three with a large mean / std ratio), against the
     transformers golden vectors (four images inside a batch of 256) and against the bf16 path, all at north_star's 1e-3; the
     setting stays an opt-in and `value` stays the bf16 step (include/mmiss.h)."""
     enc, small, W, co = b32_256
@@ -127,10 +127,12 @@ def test_b32_bs256_fp8_setting_on_the_persistent_kernels_holds_the_bar(b32_256):
         again = enc.encode_image(px)
     finally:
         enc.set_precision("bf16")
-    # 12 QKV, 11 FC1 + 11 FC2 + 11 out-projections (the pruned last layer's three run on the 128-row bf16 kernels), 11 attentions -> MXFP8
+    # 12 QKV + 11 FC1 on the persistent kernel (450 / 600 tiles of 256 x 256); 11 FC2 + 11 out-projections (150 such tiles: one short
+    # round, measured slower there) on the BM x 128 tile kernel; the pruned last layer's three GEMMs on the 128-row bf16 kernels;
+    # 11 attentions -> MXFP8
     assert kern.get("gemm_fp8_bias_p256", 0) == 12 and kern.get("gemm_fp8_qgelu_mx_p256", 0) == 11, kern
-    assert kern.get("gemm_fp8_bias_resid16_p256", 0) == 22 and kern.get("attention_mx", 0) == 11 and kern.get("attention", 0) == 1, kern
-    assert not any(k.startswith("gemm_fp8") and not k.endswith("_p256") for k in kern), kern
+    assert kern.get("gemm_fp8_bias_resid16", 0) == 22 and kern.get("attention_mx", 0) == 11 and kern.get("attention", 0) == 1, kern
+    assert set(k for k in kern if k.startswith("gemm_fp8")) == {"gemm_fp8_bias_p256", "gemm_fp8_qgelu_mx_p256", "gemm_fp8_bias_resid16"}, kern
     sub = np.concatenate([[5, 77, 200], np.arange(0, 256, 13)])[:24]
     d = 1 - _cos(out[sub], co.embed_images(px[sub], W, s))
     d16 = 1 - _cos(out, ref16)
