@@ -396,12 +396,9 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
     // partial statistics per 16 columns, the skinny QKV / FC1 GEMMs apply (mean, rstd) in their epilogue. 24 of the ~99
     // launches of a ViT-B/32 request disappear. Option skinny_fold = 0 keeps the LayerNorm kernels.
     const bool sfold = plain && !fp8 && skinny_fold_ok(tw, M);
-    // ... and every skinny launch touches the lines of the NEXT skinny launch's weights (GemmEpi::pf; round 6, VERDICT r5 next #8;
-    // option skinny_prefetch, measured in profiles/single_request_r06.txt)
-    const bool spf = sfold && mmiss_option("skinny_prefetch", 0) != 0;
-    auto set_pf = [&](GemmEpi& e_, const DevBuf& w, int N_, int K_) {
-        if (spf && w.p) { e_.pf = w.p; e_.pf_blocks = N_ / 16; e_.pf_block_bytes = 16 * K_ * 2; }
-    };
+    // (round 6, VERDICT r5 next #8, tried and removed: every skinny launch touching the weight lines of the NEXT skinny launch — one
+    // dword per 128-byte line, workgroup L taking blocks L, L + grid, ... so that they land in the L2 of the XCD that reads them
+    // next — made the request 3 % SLOWER, 0.4603 against 0.4466 ms per encode, same bits: profiles/single_request_r06.txt)
     const int parts = d / 64;
     const bool have_embed_stats16 = tw.embed_stats16;   // (the one-request embedding stage already wrote xb + the 16-column statistics)
     tw.embed_stats16 = false;
@@ -482,7 +479,6 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         } else if (sfold) {
             ep.bias = L.bqkv_f.as<float>(); ep.aux = L.cqkv.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = d / 16; ep.ln_eps = eps; ep.stats16 = 1;
-            set_pf(ep, L.wo, d, d);   // (the attention kernel in between reads no weights)
             MM_TRY(launch_gemm_skinny_fold(st, MMISS_EPI_LNFOLD_BF16, tw.xb.p, L.wqkv_f.p, ep, M, 3 * d, d));
         } else {
             if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln1g.as<float>(), L.ln1b.as<float>(), tw.h.p, M, d, eps));
@@ -542,7 +538,6 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             if (p160(d, d)) MM_TRY(launch_gemm160p(st, tw.ctx.p, L.wo.p, ep, padded(160), d, d));
             else MM_TRY(launch_gemm_resid16(st, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         } else {
-            if (sfold) set_pf(ep, L.w1_f, tw.mlp, d);
             MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.ctx.p, L.wo.p, ep, padded(bm_d), d, d));
         }
         ep = GemmEpi{};
@@ -584,7 +579,6 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
         } else if (sfold) {
             ep.bias = L.b1_f.as<float>(); ep.aux = L.c1.as<float>();
             ep.ln_stats = tw.stats.as<float>(); ep.ln_parts = d / 16; ep.ln_eps = eps; ep.stats16 = 1;
-            set_pf(ep, L.w2, d, tw.mlp);
             MM_TRY(launch_gemm_skinny_fold(st, MMISS_EPI_LNFOLD_QGELU_BF16, tw.xb.p, L.w1_f.p, ep, M, tw.mlp, d));
         } else {
             if (resid16) MM_TRY(launch_layernorm16(st, tw.xb.as<uint16_t>(), L.ln2g.as<float>(), L.ln2b.as<float>(), tw.h.p, M, d, eps));
@@ -606,7 +600,6 @@ int run_layers(mmiss_encoder* e, Tower& tw, int B, bool causal, hipStream_t st) 
             if (p160(d, tw.mlp)) MM_TRY(launch_gemm160p(st, tw.u.p, L.w2.p, ep, padded(160), d, tw.mlp));
             else MM_TRY(launch_gemm_resid16(st, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         } else {
-            if (sfold && l + 1 < tw.layers) set_pf(ep, tw.L[l + 1].wqkv_f, 3 * d, d);
             MM_TRY(launch_gemm(st, MMISS_EPI_BIAS_RESID_F32, bm_d, tw.u.p, L.w2.p, ep, padded(bm_d), d, tw.mlp));
         }
         MM_TRY(tap(l + 1));

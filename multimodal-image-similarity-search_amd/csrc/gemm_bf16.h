@@ -44,12 +44,6 @@ struct GemmEpi {
     // LNFOLD epilogues of the persistent kernel, K > 768: (mean, rstd) of every row FINISHED, [M][2] (ln_finalize_kernel) —
     // the raw partials of a 256-row tile (K / 64 x 8 bytes per row) no longer fit beside the staging buffers
     const float* ln_final;
-    // skinny kernels, one request at a time (round 6, option skinny_prefetch): the NEXT skinny launch's weights — pf_blocks blocks
-    // of pf_block_bytes (16 weight rows: what one of ITS workgroups streams). Workgroup L of this launch touches one dword per
-    // 128-byte line of blocks L, L + G, ... (G = this grid, a multiple of 8: the same XCD under round-robin placement), so the
-    // next launch's first round trip finds its lines in that XCD's L2. Never read for their values. null = off.
-    const void* pf;
-    int pf_blocks, pf_block_bytes;
 };
 
 #define MMISS_EPI_GROUPMAX_F32 5  // internal: out f32 [M, N/16] = max over the lane's 16 n (see decode below)

@@ -76,7 +76,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
         if (wave < MT && m < M) pre_res = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(ep.out) + (size_t)m * ep.ldo + n_pre);
     }
 
-    uint32_t pfv[4] = {0u, 0u, 0u, 0u};   // (prefetch of the next launch's weights: see the K loop)
     // U k-steps per trip: every load of the trip (U weight fragments from HBM/MALL, U*MT activation fragments from L2)
     // is issued before its first MFMA - the loop is bound by memory latency, so what matters is loads in flight.
     // The launcher picks NW so that a wave's whole K-slice is one trip where registers allow (U*(1+MT)*4 VGPRs).
@@ -94,18 +93,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
             if (k == 0) {
                 const int m = m_base + wave * 16 + fr;
                 if (wave < MT && m < M) row_mean_rstd(m, pre_mean, pre_rstd);
-            }
-        }
-        // the next launch's weight lines toward this XCD's L2 (GemmEpi::pf): issued behind this launch's own first operand loads
-        // (younger: no wait of the K loop's first trip depends on them), never waited for before the end of the kernel
-        if (k == 0 && ep.pf) {
-            const int G = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
-            const int lines = ep.pf_block_bytes >> 7, spb = (lines + NW * 64 - 1) / (NW * 64);   // loads per thread and block
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int blk = L + (i / spb) * G, ln = tid + (i % spb) * (NW * 64);
-                if (blk < ep.pf_blocks && ln < lines && i / spb < 4)
-                    pfv[i] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(ep.pf) + (size_t)blk * ep.pf_block_bytes + (size_t)ln * 128);
             }
         }
 #pragma unroll
@@ -199,7 +186,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const __bf16* __re
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(ep.out) + ((size_t)img * ep.p1 + 1 + pt) * ep.ldo + n) = v + pos;
         }
     }
-    asm volatile("" ::"v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]));   // (the prefetch loads are not dead code; their wait falls HERE, behind everything)
 }
 
 // Whether launch_gemm should take the skinny path for `mv` valid rows.
