@@ -775,7 +775,14 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
                 for (int j = 0; j < 8; ++j) acc[i][j] = acc[i][j] * iv;
             }
         }
+        // Appending to a query's list is an atomic add WITH return (the slot) followed by the stores into that slot. Round 6: the
+        // slots of a tile's eight 16-query blocks are requested FIRST — one atomic per (lane, block) that has something to append,
+        // for all of the lane's passing rows at once — and used after the last request: one exposed round trip per tile and wave.
+        // Requested where they were used (rounds 3-5) they were up to eight sequential round trips of ~0.4 us per tile with the
+        // other waves waiting at the next barrier: the widen pass of the bench step took 78 us with 66 rows per query passing,
+        // 117 us with 147, against 43 us with 10 (tools/sweep_probe.py, profiles/sweep_r06.txt).
         if constexpr (FILTER == 2) {
+            int npass[8], pos[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int m = bm * 256 + wm * 128 + j * 16 + fr;
@@ -787,15 +794,30 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
                     mx = i < 3 ? mm_max3(mx, acc[i][j][3], acc[i + 1][j][0]) : mm_max2(mx, acc[i][j][3]);
                 }
                 mx *= WSCALE;   // (fp8 rows: the codes are 128 x the stored values; a power of two, exact)
+                int c = 0;
                 if (mx >= tau_r[j]) {   // rare: some row of this lane's 16 reaches the query's threshold (tau_r = +inf for pad queries)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c += (acc[i][j][r] * WSCALE >= tau_r[j] && n0 + i * 16 + r < ep.p0) ? 1 : 0;
+                }
+                npass[j] = c;
+                pos[j] = 0;
+                if (c > 0) pos[j] = atomicAdd(flt.cnt + m, c);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (npass[j] > 0) {
+                    const int m = bm * 256 + wm * 128 + j * 16 + fr;
+                    int p = pos[j];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int n = n0 + i * 16 + r;
                             if (acc[i][j][r] * WSCALE >= tau_r[j] && n < ep.p0) {
-                                const int pos = atomicAdd(flt.cnt + m, 1);
-                                if (pos < flt.cap) flt.buf_g[(size_t)m * flt.cap + pos] = n;
+                                if (p < flt.cap) flt.buf_g[(size_t)m * flt.cap + p] = n;
+                                ++p;
                             }
                         }
                 }
@@ -804,6 +826,8 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
             }
             continue;
         }
+        // (FILTER = 1: a block's maximum and its slot wait in two of the block's own — consumed, zeroed — accumulator registers
+        // until the second loop: sixteen more live registers were four spilled ones)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float mx = -INFINITY;
@@ -831,15 +855,26 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
             const int m = bm * 256 + wm * 128 + j * 16 + fr;
             mx *= WSCALE;
             if constexpr (FILTER == 1) {
-                if (mx >= tau_r[j] && mx > -INFINITY) {  // (tau_r = +inf for pad queries; -inf maxima = all-pad groups)
-                    const int pos = atomicAdd(flt.cnt + m, 1);
-                    if (pos < flt.cap) {
-                        flt.buf_s[(size_t)m * flt.cap + pos] = mx;
-                        flt.buf_g[(size_t)m * flt.cap + pos] = g;
-                    }
-                }
+                int pos_ = -1;
+                if (mx >= tau_r[j] && mx > -INFINITY)   // (tau_r = +inf for pad queries; -inf maxima = all-pad groups)
+                    pos_ = atomicAdd(flt.cnt + m, 1);
+                acc[0][j][0] = mx;
+                acc[0][j][1] = __int_as_float(pos_);
             } else {
                 if (m < ep.m_valid) out[(size_t)m * ep.ldo + g] = mx;
+            }
+        }
+        if constexpr (FILTER == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = bm * 256 + wm * 128 + j * 16 + fr;
+                const int pos_ = __float_as_int(acc[0][j][1]);
+                if (pos_ >= 0 && pos_ < flt.cap) {
+                    flt.buf_s[(size_t)m * flt.cap + pos_] = acc[0][j][0];
+                    flt.buf_g[(size_t)m * flt.cap + pos_] = g;
+                }
+                acc[0][j][0] = 0.f;
+                acc[0][j][1] = 0.f;
             }
         }
     }
