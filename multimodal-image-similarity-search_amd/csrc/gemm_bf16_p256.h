@@ -782,7 +782,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
         // other waves waiting at the next barrier: the widen pass of the bench step took 78 us with 66 rows per query passing,
         // 117 us with 147, against 43 us with 10 (tools/sweep_probe.py, profiles/sweep_r06.txt).
         if constexpr (FILTER == 2) {
-            int npass[8], pos[8];
+            // ... and a lane keeps WHICH of its 16 rows pass as a bit mask: the slow path is 16 compares into the mask, one popcount, one
+            // atomic, and later a loop over the set bits (one or two) — as 16 + 16 branches around a counter and a store per block it
+            // was ~2500 vector instructions per wave and tile on an index where most blocks have a passing row, two waves per SIMD.
+            uint32_t pmask[8];
+            int pos[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int m = bm * 256 + wm * 128 + j * 16 + fr;
@@ -794,35 +798,33 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const IN* __restrict__
                     mx = i < 3 ? mm_max3(mx, acc[i][j][3], acc[i + 1][j][0]) : mm_max2(mx, acc[i][j][3]);
                 }
                 mx *= WSCALE;   // (fp8 rows: the codes are 128 x the stored values; a power of two, exact)
-                int c = 0;
+                uint32_t pm = 0;
                 if (mx >= tau_r[j]) {   // rare: some row of this lane's 16 reaches the query's threshold (tau_r = +inf for pad queries)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) c += (acc[i][j][r] * WSCALE >= tau_r[j] && n0 + i * 16 + r < ep.p0) ? 1 : 0;
+                        for (int r = 0; r < 4; ++r)
+                            pm |= (acc[i][j][r] * WSCALE >= tau_r[j] && (whole || n0 + i * 16 + r < ep.p0)) ? (1u << (i * 4 + r)) : 0u;
                 }
-                npass[j] = c;
+                pmask[j] = pm;
                 pos[j] = 0;
-                if (c > 0) pos[j] = atomicAdd(flt.cnt + m, c);
+                if (pm) pos[j] = atomicAdd(flt.cnt + m, __popc(pm));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (npass[j] > 0) {
+                uint32_t pm = pmask[j];
+                if (pm) {
                     const int m = bm * 256 + wm * 128 + j * 16 + fr;
                     int p = pos[j];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = n0 + i * 16 + r;
-                            if (acc[i][j][r] * WSCALE >= tau_r[j] && n < ep.p0) {
-                                if (p < flt.cap) flt.buf_g[(size_t)m * flt.cap + p] = n;
-                                ++p;
-                            }
-                        }
+                    while (pm) {
+                        const int b = __ffs(pm) - 1;
+                        pm &= pm - 1;
+                        if (p < flt.cap) flt.buf_g[(size_t)m * flt.cap + p] = n0 + (b >> 2) * 16 + (b & 3);
+                        ++p;
+                    }
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             continue;
         }
