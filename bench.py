@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-text", action="store_true", help="skip the informational text-tower timing")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the instrumented replay (no roofline object)")
+    ap.add_argument("--query-stream", choices=("own", "same"), default="same",
+                    help="own: the query stage of step i on a second HIP stream beside the encode of step i+1; same: one stream")
     return ap.parse_args()
 
 
@@ -184,6 +186,15 @@ def main():
     # so the GPU does not idle for the ~40 us the host needs to wake up, return through Python and launch again. Every timed
     # loop ends with drain(): all K encodes AND all K result sets are complete inside the timed region.
     pending = [None]
+    # --query-stream own: the query stage (first pass, and the widen pass query_end decides on) runs on its OWN HIP stream, ordered
+    # behind the encode that produced its embeddings by an event, so the host's wait for a step's results no longer waits for the
+    # next step's encode and the two overlap on the chip. The embeddings ping-pong between two buffers (an encode may only
+    # overwrite a buffer whose first pass is complete: event `read_done`).
+    qstream = torch.cuda.Stream(device=dev) if args.query_stream == "own" else None
+    embs = [emb, torch.empty_like(emb)] if qstream else [emb]
+    emb_alls = ([emb_all, torch.empty_like(emb_all)] if qstream else [emb_all]) if world > 1 else embs
+    read_done = [None, None]
+    cur_emb = [emb]
 
     def finish(h):
         lab, dst, cnt = h.result()
@@ -193,13 +204,27 @@ def main():
         return lab, dst, cnt
 
     def step():
-        enc.encode_image(pixel_batches[step_no[0] % NROT], out=emb)
+        sl = (step_no[0] & 1) if qstream else 0
+        e, ea = embs[sl], emb_alls[sl]
+        if qstream and read_done[sl] is not None:
+            torch.cuda.current_stream().wait_event(read_done[sl])
+        enc.encode_image(pixel_batches[step_no[0] % NROT], out=e)
         step_no[0] += 1
+        cur_emb[0] = e
         if world > 1:
-            all_gather(emb_all, emb)                     # queries: every rank searches all N*256 embeddings in its shard
+            all_gather(ea, e)                            # queries: every rank searches all N*256 embeddings in its shard
         prev, pending[0] = pending[0], None
         out = finish(prev) if prev is not None else None   # the PREVIOUS step's results, while this step's encode runs
-        pending[0] = index.query_begin(emb_all, K_TOP)
+        if qstream:
+            ready = torch.cuda.Event()
+            ready.record()                               # this step's embeddings are complete (main stream)
+            with torch.cuda.stream(qstream):
+                qstream.wait_event(ready)
+                pending[0] = index.query_begin(ea, K_TOP)
+                read_done[sl] = torch.cuda.Event()
+                read_done[sl].record()
+        else:
+            pending[0] = index.query_begin(ea, K_TOP)
         return out
 
     def drain():
@@ -257,7 +282,7 @@ def main():
     gs_timed = index.guard_stats()
     pipelined_equals_sync = None
     if world == 1 and last_out is not None:
-        lab_s, dst_s, _c = index.query(emb, K_TOP)
+        lab_s, dst_s, _c = index.query(cur_emb[0], K_TOP)
         pipelined_equals_sync = bool(torch.equal(last_out[0], lab_s) and torch.equal(last_out[1], dst_s))
     # every query of the last step is a row of the index: it must come back first, at distance ~0 (all ranks' queries, global labels)
     self_first, max_self_dist = None, None
@@ -815,6 +840,8 @@ def main():
                                           "set_precision('bf16-f32resid') keeps it f32 (5e-6, 4-5 % slower)",
                        "step_pipelining": "one deep: step i+1's encode is queued before the host waits for step i's query results "
                                           "(FlatIndex.query_begin / result()); all K result sets are complete inside the timed region",
+                       "query_stream": ("own HIP stream: the query stage of step i (first pass, widen pass) runs beside the encode of step i+1, "
+                                        "ordered behind its own encode by an event" if args.query_stream == "own" else "the encoder's stream"),
                        "ms_per_step_unpipelined": round(unpipelined * 1e3 / args.steps, 3),
                        "last_pipelined_result_equals_synchronous_query": pipelined_equals_sync,
                        "kernel_events_in_timed_region": "dominant kernel, every 7th launch",
