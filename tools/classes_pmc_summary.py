@@ -23,11 +23,17 @@ CLASSES = [  # (class, regex over the kernel name as rocprofv3 prints it — dem
     ("gemm_bf16_bias_resid16_p160_k4096 (L/14 FC2, bf16 leg)", r"gemm160p_kernel(ILi9ELi0ELi64E|<9, 0, 64>)", "fp8"),
     ("gemm8 (fp8 block-scaled GEMMs on the BM x 128 tile, round 4; L/14 bs 128)", r"gemm8_kernel", "fp8"),
     # round 5: the persistent 256 x 256 block-scaled fp8 kernel (gemm_fp8_p256.h), one class per epilogue
-    ("gemm_fp8_bias_p256 (L/14 QKV, fp8)", r"gemm256p8_kernel(ILi0ELi0E|<0, 0>)", "fp8"),
-    ("gemm_fp8_qgelu_mx_p256 (L/14 FC1, fp8 -> MXFP8)", r"gemm256p8_kernel(ILi1ELi0E|<1, 0>)", "fp8"),
-    ("gemm_fp8_bias_resid16_p256 (L/14 out-proj + FC2, fp8)", r"gemm256p8_kernel(ILi3ELi0E|<3, 0>)", "fp8"),
+    ("gemm_fp8_bias_p256 (L/14 QKV, fp8)", r"gemm256p8_kernel(ILi0ELi0ELi0E|<0, 0, 0>)", "fp8"),
+    ("gemm_fp8_qgelu_mx_p256 (L/14 FC1, fp8 -> MXFP8)", r"gemm256p8_kernel(ILi1ELi0ELi0E|<1, 0, 0>)", "fp8"),
+    ("gemm_fp8_bias_resid16_p256 (L/14 out-proj + FC2, fp8)", r"gemm256p8_kernel(ILi3ELi0ELi0E|<3, 0, 0>)", "fp8"),
     ("attention_stream (L/14: 257 tokens, bf16 + MXFP8 output; round 5)", r"attention_(stream|long)_kernel", "fp8"),
     ("layernorm16 -> MXFP8 (L/14, 16 columns per lane)", r"layernorm16_mxfp8", "fp8"),
+    # round 6: ViT-B/32 bs 256 under the fp8 setting (tools/b32_kernel_table.py): K = 768 = three K-tile pairs per tile (ODD form)
+    ("gemm_fp8_bias_p256 (B/32 QKV, fp8, K = 768)", r"gemm256p8_kernel(ILi0ELi0ELi1E|<0, 0, 1>)", "b32fp8"),
+    ("gemm_fp8_qgelu_mx_p256 (B/32 FC1, fp8 -> MXFP8, K = 768)", r"gemm256p8_kernel(ILi1ELi0ELi1E|<1, 0, 1>)", "b32fp8"),
+    ("gemm_fp8_bias_resid16 (B/32 FC2 + out-proj, fp8 tile kernel)", r"gemm8_kernel", "b32fp8"),
+    ("attention_mx (B/32: 50 tokens, MXFP8 output)", r"attention_heads_kernel", "b32fp8"),
+    ("layernorm16 -> MXFP8 (B/32, d = 768)", r"layernorm16_mxfp8", "b32fp8"),
 ]
 COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAVES",
             "GRBM_GUI_ACTIVE", "SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
@@ -43,7 +49,7 @@ def load(d):
 
 
 def main(root, out):
-    runs = {"bench": load(root + "/bench"), "fp8": load(root + "/fp8")}
+    runs = {"bench": load(root + "/bench"), "fp8": load(root + "/fp8"), "b32fp8": load(root + "/b32fp8")}
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["class", "run", "symbols", "dispatches"] + [c + "_per_dispatch" for c in COUNTERS] +

@@ -5,7 +5,7 @@
 # each rocprofv3 run with --kernel-trace + --pmc only (gpurun refuses --pmc next to the API trace domains).
 # Usage (through gpurun): bash tools/profile_classes_pmc.sh r03   ->  gpurun_out/classes_pmc_r03/summary.csv
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/classes_pmc_$TAG
@@ -22,6 +22,9 @@ for SET in "$SET1" "$SET2"; do
   echo "bench pass $i rc=$?"
   rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/fp8/p$i -o pmc -- python3 tools/l14_fp8_bench.py > $OUT/fp8_p$i.log 2>&1
   echo "fp8 pass $i rc=$?"
+  # round 6: ViT-B/32 bs 256 under the fp8 setting (K = 768 on the persistent kernel, the 50-key attention writing MXFP8)
+  rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/b32fp8/p$i -o pmc -- python3 tools/b32_kernel_table.py > $OUT/b32fp8_p$i.log 2>&1
+  echo "b32 fp8 pass $i rc=$?"
 done
 grep -h "Missing" $OUT/*.log | sed 's/.*Missing/Missing/' | sort -u
 cat $OUT/vmem_counters_available.txt; echo
