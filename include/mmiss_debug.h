@@ -82,7 +82,8 @@ int mmiss_dbg_layernorm_mxfp8(int device, void* hip_stream, const float* x, cons
 int mmiss_dbg_layernorm16_mxfp8(int device, void* hip_stream, const void* x_bf16, const float* gamma, const float* beta,
                                 void* out8, void* out_scale, int32_t M, int32_t d, float eps);
 /* attention whose output leaves the kernel as MXFP8 (the fp8 out-projection's A operand): qkv bf16 [B*T, 3*H*64] -> ctx8 e4m3
- * [B*T, H*64] + ctx_scale (permuted E8M0, 16 * ceil(H*64 / 512) bytes per row); non-causal, 129 <= T <= 288 */
+ * [B*T, H*64] + ctx_scale (permuted E8M0, 16 * ceil(H*64 / 512) bytes per row); non-causal, 1 <= T <= 288 (round 6: the one-pass
+ * kernels for T <= 128 too) */
 int mmiss_dbg_attention_mx(int device, void* hip_stream, const void* qkv, void* ctx8, void* ctx_scale, int32_t B, int32_t T,
                            int32_t H);
 /* epi: 0 out bf16 = acc * wscale[n] + bias[n]; 1 out e4m3 + out_scale = mx(quick_gelu(.)); 2 out f32 += . ; bm = 128 | 160 | 192 */

@@ -1550,7 +1550,7 @@ extern "C" int mmiss_dbg_layernorm16_mxfp8(int device, void* hip_stream, const v
 }
 
 // qkv bf16 [B*T, 3*H*64] -> the attention output as MXFP8: ctx8 e4m3 [B*T, H*64] + permuted E8M0 scales [B*T, 16 * ceil(H*64 / 512)]
-// (non-causal, 129 <= T <= 288: the long-sequence form)
+// (non-causal; T <= 128: the one-pass kernels, 129 <= T <= 288: the long-sequence form)
 extern "C" int mmiss_dbg_attention_mx(int device, void* hip_stream, const void* qkv, void* ctx8, void* ctx_scale, int32_t B,
                                       int32_t T, int32_t H) {
     if (!qkv || !ctx8 || !ctx_scale) MM_FAIL(MMISS_ERR_ARG, "mmiss_dbg_attention_mx: null pointer");
