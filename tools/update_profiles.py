@@ -121,7 +121,8 @@ first: {d['config']['every_query_of_the_last_step_finds_itself_first']} (max sel
 The same step on an index of RANDOM rows (`random_index`, what rounds 1–5 quoted): **{c1['images_per_s'] / 1e3:.1f} k images/s**, {c1['ms_per_step']:.3f} ms/step =
 {c1['vs_headline_step']:.3f} × the headline step; query stage {c1['query_stage_ms']['headline_index_first_pass_plus_widen']:.3f} ms on the headline's index against {c1['query_stage_ms']['headline_index_first_pass_only_guard_off']:.3f} ms for its unproven
 first pass and {c1['query_stage_ms']['random_index']:.3f} ms on the random index. Two batches in flight (`two_batches_in_flight`): **{d['two_batches_in_flight']['images_per_s'] / 1e3:.1f} k images/s**.
-Kernel time per step in the profiled trace: {ktot:.2f} ms — the step is the sum of its kernels.
+(The rocprofv3 trace of this round also holds the 391 encodes that build the index before the timed region: its per-kernel AVERAGES below
+are comparable with the bench's, its totals are not per step.)
 
 | kernel class (rocprofv3 symbol) | calls/step | avg µs: HIP events in the bench (rocprofv3) | TFLOP/s | share | fabric bytes per launch (class) | matrix pipes busy |
 |---|---|---|---|---|---|---|
