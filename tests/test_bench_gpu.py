@@ -38,19 +38,23 @@ def test_bench_two_ranks_gloo_dry_run():
 
 
 @pytest.mark.timeout(600)
-def test_bench_one_gpu_pipelined_steps_deliver_the_synchronous_results():
+@pytest.mark.parametrize("query_stream", ["same", "own"])
+def test_bench_one_gpu_pipelined_steps_deliver_the_synchronous_results(query_stream):
     """N = 1, the driver's default form with a short run: the timed steps are pipelined one deep (query_begin / query_end);
     the line says what it did, times the unpipelined form beside it, and its last pipelined result set is the synchronous
     query's, id for id and bit for bit."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # (--query-stream own: the query stage on a second HIP stream beside the next encode, embeddings ping-ponging between two
+    # buffers behind events — the same results, id for id and bit for bit)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--retrieval-rows", "0",
-           "--no-cpu-baseline", "--no-text"]
+           "--no-cpu-baseline", "--no-text", "--query-stream", query_stream]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     cfg = out["config"]
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
     assert "query_begin" in cfg["step_pipelining"] and cfg["ms_per_step_unpipelined"] > 0
+    assert ("own HIP stream" in cfg["query_stream"]) == (query_stream == "own")
     assert cfg["last_pipelined_result_equals_synchronous_query"] is True
     # round 6: `value` is timed on configs[1] AS WRITTEN — the index holds the embeddings of the step's own images, every query is
     # a row of it (and must come back first), and the exactness guard widens them (random-weight embeddings: pairwise cosine 0.99)
