@@ -227,7 +227,10 @@ def test_block_scaled_gemm_on_identical_bytes(env, epi, bm, M, N, K):
                                           # FC1 -> MXFP8 (600 tiles: two rounds + halves), out-projection (150 tiles: one short round), FC2
                                           # (K = 3072); a ragged last row block with five pairs per tile
                                           (0, 12800, 12800, 2304, 768), (1, 12800, 12800, 3072, 768), (3, 12800, 12800, 768, 768),
-                                          (3, 12800, 12800, 768, 3072), (1, 2048, 1900, 512, 1280)])
+                                          (3, 12800, 12800, 768, 3072), (1, 2048, 1900, 512, 1280),
+                                          # ... the corners of the tile list with an odd pair count: 257 tiles (one round + ONE tile, run as two half
+                                          # tiles), 516 tiles (two rounds + 4), seven pairs per tile with a ragged block, 128 tiles (half the chip)
+                                          (0, 65792, 65792, 256, 1280), (1, 66048, 66000, 512, 768), (0, 4096, 4000, 256, 1792), (3, 8192, 8192, 1024, 768)])
 def test_persistent_fp8_gemm_equals_the_tile_kernel_bit_for_bit(env, epi, M, mv, N, K):
     """gemm256p8_kernel (round 5: one workgroup per CU, ONE K-tile stream over its tiles, staggered wave halves, the block
     scales through an LDS ring) against gemm8_kernel (BM x 128 tiles) on the same bytes: both sum a row's K-tiles in ascending
