@@ -29,7 +29,6 @@
 #include "gemm_bf16.h"
 
 typedef __attribute__((ext_vector_type(8))) int v8i32;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MMISS_EPI8_BIAS_BF16 0        // out bf16 [M,N] = acc * sw[n] + bias[n]                          (QKV)
 #define MMISS_EPI8_QGELU_MXFP8 1      // out e4m3 [M,N] + E8M0 scales = mx(quick_gelu(acc * sw[n] + bias[n]))  (FC1)
@@ -571,11 +570,7 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
     const int lane = threadIdx.x & 63;
     const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
     if (r0 >= M) return;
-    // Round 6: the arithmetic on PAIRS of columns (v_pk_add / mul / fma_f32: two f32 operations per issue slot). The kernel was bound
-    // by vector issue, not by memory — ~200 single instructions per row and wave, 32 waves per CU at ViT-L/14's 33 024 rows: 22 us for
-    // 102 MB (4.7 TB/s) — and none of them were packed. Per element the operations and their order are the ones of the first form
-    // ((x - mean) rstd, then fma with gamma, beta); the row sums associate differently (last-bit differences of mean / rstd).
-    f32x2 gm[NS][4], bb[NS][4];
+    float gm[NS][8], bb[NS][8];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int c = i * 512 + lane * 8;
@@ -583,8 +578,8 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 g0 = live ? *reinterpret_cast<const f32x4*>(gamma + c) : z, g1 = live ? *reinterpret_cast<const f32x4*>(gamma + c + 4) : z;
         const f32x4 b0 = live ? *reinterpret_cast<const f32x4*>(beta + c) : z, b1 = live ? *reinterpret_cast<const f32x4*>(beta + c + 4) : z;
-        gm[i][0] = f32x2{g0[0], g0[1]}; gm[i][1] = f32x2{g0[2], g0[3]}; gm[i][2] = f32x2{g1[0], g1[1]}; gm[i][3] = f32x2{g1[2], g1[3]};
-        bb[i][0] = f32x2{b0[0], b0[1]}; bb[i][1] = f32x2{b0[2], b0[3]}; bb[i][2] = f32x2{b1[0], b1[1]}; bb[i][3] = f32x2{b1[2], b1[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gm[i][e] = g0[e]; gm[i][4 + e] = g1[e]; bb[i][e] = b0[e]; bb[i][4 + e] = b1[e]; }
     }
     u32x4 raw[RW][NS];
 #pragma unroll
@@ -599,50 +594,48 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_wide_kernel(const uint1
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
         const int r = r0 + j;
-        f32x2 v[NS][4];
-        f32x2 s2 = f32x2{0.f, 0.f};
+        float v[NS][8];
+        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v[i][w] = f32x2{__uint_as_float(raw[j][i][w] << 16), __uint_as_float(raw[j][i][w] & 0xFFFF0000u)};
-            s2 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            for (int w = 0; w < 4; ++w) {
+                v[i][2 * w] = __uint_as_float(raw[j][i][w] << 16);
+                v[i][2 * w + 1] = __uint_as_float(raw[j][i][w] & 0xFFFF0000u);
+            }
+            s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
         }
-        const float mean = wave_sum(s2[0] + s2[1]) * (1.0f / (float)D);
-        const f32x2 mean2 = f32x2{mean, mean};
-        f32x2 q2 = f32x2{0.f, 0.f};
+        const float mean = wave_sum(s) * (1.0f / (float)D);
+        float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const bool live = (i + 1) * 512 <= D || i * 512 + lane * 8 < D;   // (a column that does not exist adds nothing to the variance)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                v[i][w] = v[i][w] - mean2;
-                if (live) q2 = __builtin_elementwise_fma(v[i][w], v[i][w], q2);
+            for (int e = 0; e < 8; ++e) {
+                const float t = v[i][e] - mean;
+                q += live ? t * t : 0.f;
             }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(q2[0] + q2[1]) * (1.0f / (float)D) + eps);
-        const f32x2 rstd2 = f32x2{rstd, rstd};
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            f32x2 y[4];
+            float y[8];
             float amax = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                y[w] = __builtin_elementwise_fma(v[i][w] * rstd2, gm[i][w], bb[i][w]);
-                amax = fmaxf(amax, fmaxf(fabsf(y[w][0]), fabsf(y[w][1])));
+            for (int e = 0; e < 8; ++e) {
+                y[e] = (v[i][e] - mean) * rstd * gm[i][e] + bb[i][e];
+                amax = fmaxf(amax, fabsf(y[e]));
             }
             amax = fmaxf(amax, __shfl_xor(amax, 1));
             amax = fmaxf(amax, __shfl_xor(amax, 2));
             int e8;
             float inv;
             mx_scale_of(amax, e8, inv);
-            const f32x2 inv2 = f32x2{inv, inv};
             const int c = i * 512 + lane * 8;
             if (r < M && ((i + 1) * 512 <= D || c < D)) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) y[w] = y[w] * inv2;
                 u32x2 pk;
-                pk[0] = pack_fp8x4(y[0][0], y[0][1], y[1][0], y[1][1]);
-                pk[1] = pack_fp8x4(y[2][0], y[2][1], y[3][0], y[3][1]);
+                pk[0] = pack_fp8x4(y[0] * inv, y[1] * inv, y[2] * inv, y[3] * inv);
+                pk[1] = pack_fp8x4(y[4] * inv, y[5] * inv, y[6] * inv, y[7] * inv);
                 *reinterpret_cast<u32x2*>(out + (size_t)r * D + c) = pk;
                 if ((lane & 3) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
             }
@@ -663,12 +656,12 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_1024_kernel(const uint1
     const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
     if (r0 >= M) return;
     const int c = lane * 16;
-    f32x2 gm[8], bb[8];   // (round 6: pairs of columns, packed f32 arithmetic — see layernorm16_mxfp8_wide_kernel)
+    float gm[16], bb[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c + 4 * i), b = *reinterpret_cast<const f32x4*>(beta + c + 4 * i);
-        gm[2 * i] = f32x2{g[0], g[1]}; gm[2 * i + 1] = f32x2{g[2], g[3]};
-        bb[2 * i] = f32x2{b[0], b[1]}; bb[2 * i + 1] = f32x2{b[2], b[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gm[4 * i + e] = g[e]; bb[4 * i + e] = b[e]; }
     }
     u32x4 raw[RW][2];
 #pragma unroll
@@ -680,42 +673,40 @@ __global__ __launch_bounds__(256) void layernorm16_mxfp8_1024_kernel(const uint1
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
         const int r = r0 + j;
-        f32x2 v[8];
-        f32x2 s2 = f32x2{0.f, 0.f};
+        float v[16];
+        float s = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) v[4 * h + w] = f32x2{__uint_as_float(raw[j][h][w] << 16), __uint_as_float(raw[j][h][w] & 0xFFFF0000u)};
-            s2 += (v[4 * h] + v[4 * h + 1]) + (v[4 * h + 2] + v[4 * h + 3]);
+            for (int w = 0; w < 4; ++w) {
+                v[8 * h + 2 * w] = __uint_as_float(raw[j][h][w] << 16);
+                v[8 * h + 2 * w + 1] = __uint_as_float(raw[j][h][w] & 0xFFFF0000u);
+            }
+            s += ((v[8 * h] + v[8 * h + 1]) + (v[8 * h + 2] + v[8 * h + 3])) + ((v[8 * h + 4] + v[8 * h + 5]) + (v[8 * h + 6] + v[8 * h + 7]));
         }
-        const float mean = wave_sum(s2[0] + s2[1]) * (1.0f / (float)D);
-        const f32x2 mean2 = f32x2{mean, mean};
-        f32x2 q2 = f32x2{0.f, 0.f};
+        const float mean = wave_sum(s) * (1.0f / (float)D);
+        float q = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = v[e] - mean2;
-            q2 = __builtin_elementwise_fma(v[e], v[e], q2);
+        for (int e = 0; e < 16; ++e) {
+            const float t = v[e] - mean;
+            q += t * t;
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(q2[0] + q2[1]) * (1.0f / (float)D) + eps);
-        const f32x2 rstd2 = f32x2{rstd, rstd};
-        f32x2 y[8];
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
+        float y[16];
         float amax = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            y[e] = __builtin_elementwise_fma(v[e] * rstd2, gm[e], bb[e]);
-            amax = fmaxf(amax, fmaxf(fabsf(y[e][0]), fabsf(y[e][1])));
+        for (int e = 0; e < 16; ++e) {
+            y[e] = (v[e] - mean) * rstd * gm[e] + bb[e];
+            amax = fmaxf(amax, fabsf(y[e]));
         }
         amax = fmaxf(amax, __shfl_xor(amax, 1));
         int e8;
         float inv;
         mx_scale_of(amax, e8, inv);
-        const f32x2 inv2 = f32x2{inv, inv};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) y[e] = y[e] * inv2;
         if (r < M) {
             u32x4 pk;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pk[i] = pack_fp8x4(y[2 * i][0], y[2 * i][1], y[2 * i + 1][0], y[2 * i + 1][1]);
+            for (int i = 0; i < 4; ++i) pk[i] = pack_fp8x4(y[4 * i] * inv, y[4 * i + 1] * inv, y[4 * i + 2] * inv, y[4 * i + 3] * inv);
             *reinterpret_cast<u32x4*>(out + (size_t)r * D + c) = pk;
             if constexpr (!PACKS) {
                 if ((lane & 1) == 0) out_scale[(size_t)r * ld_os + mx_scale_offset(c >> 5)] = (uint8_t)e8;
