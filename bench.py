@@ -200,7 +200,10 @@ def main():
     cur_emb = [emb]
 
     def finish(h):
-        lab, dst, cnt = h.result()
+        return finish_results(h.result())
+
+    def finish_results(res):
+        lab, dst, cnt = res
         if world > 1:
             lab_all, dst_all = exchange_topk(lab, dst, world, all_gather=all_gather)  # X1: ONE packed all-gather
             return merge_topk(dst_all, lab_all)
@@ -218,6 +221,10 @@ def main():
         if world > 1:
             all_gather(ea, e)                            # queries: every rank searches all N*256 embeddings in its shard
         prev, pending[0] = pending[0], None
+        if prev is not None and qstream is None:
+            # the PREVIOUS step's results and this step's first pass back to back (FlatIndex.query_next: no Python between the two)
+            res, pending[0] = index.query_next(prev, ea, K_TOP)
+            return finish_results(res)
         out = finish(prev) if prev is not None else None   # the PREVIOUS step's results, while this step's encode runs
         if qstream:
             ready = torch.cuda.Event()

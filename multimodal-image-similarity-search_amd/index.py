@@ -118,7 +118,22 @@ class FlatIndex:
         may queue other GPU work on the same stream (the next batch's encode) — but no other call on this index."""
         return self._query(queries, k, split=True)
 
-    def _query(self, queries, k: int, split: bool):
+    def query_next(self, pending: "PendingQuery", queries, k: int):
+        """`pending.result()` and `query_begin(queries, k)` back to back -> (results of `pending`, the new PendingQuery). Everything
+        Python has to do for the NEW query (layout checks, output buffers) happens BEFORE the pending one is ended, so between the
+        last operation of its widen pass and the first kernel of the new first pass lie two C calls and nothing else. In a serving
+        loop that keeps one query batch open per step (bench.py) the GPU idled ~87 us per step there (rocprofv3 kernel trace of
+        round 6: the gap between the widen pass's count readback and prep_queries_kernel)."""
+        q, outs = self._prepare(queries, k)
+        prev = pending.result()
+        with self._call_lock:
+            self._sync_stream(q)
+            _lib.check(self._lib.mmiss_index_query_begin(self._h, _lib.ptr(q), int(q.shape[0]), int(k), _lib.ptr(outs[0]), _lib.ptr(outs[1]),
+                                                         _lib.ptr(outs[2])))
+            self._query_gen += 1
+            return prev, PendingQuery(self, q, outs, self._query_gen)
+
+    def _prepare(self, queries, k: int):
         q = self._vecs(queries)
         Q = int(q.shape[0])
         if _is_torch(q) and q.is_cuda:
@@ -133,6 +148,11 @@ class FlatIndex:
             lab = np.empty((Q, k), dtype=np.int64)
             dist = np.empty((Q, k), dtype=np.float32)
             cnt = np.empty((Q,), dtype=np.int32)
+        return q, (lab, dist, cnt)
+
+    def _query(self, queries, k: int, split: bool):
+        q, (lab, dist, cnt) = self._prepare(queries, k)
+        Q = int(q.shape[0])
         with self._call_lock:  # stream hand-over + call are one unit per handle (threads: pipeline.BatchLanes)
             self._sync_stream(q)
             fn = self._lib.mmiss_index_query_begin if split else self._lib.mmiss_index_query

@@ -573,6 +573,45 @@ def test_query_begin_end_equals_query(mods, device_io, force_widen):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("force_widen", [0, 1])
+@pytest.mark.parametrize("device_io", [False, True])
+def test_query_next_chains_batches_like_separate_queries(mods, device_io, force_widen):
+    """FlatIndex.query_next(pending, queries, k) = pending.result() + query_begin(queries, k) with nothing but two C calls between
+    them (round 6: the serving loop of bench.py): a chain of batches of different sizes gives, batch for batch, what query()
+    gives — ids, distance bits, counts — with and without the widen pass, host and device tensors."""
+    import torch
+    from mmiss_amd import _lib
+
+    FlatIndex, _, _, ro = mods
+    N, D, k = 30000, 256, 10
+    c = _corpus(N, D, seed=91)
+    labels = np.arange(N, dtype=np.int64) * 2
+    idx = FlatIndex(D, "f16")
+    idx.add(c, labels)
+    stored = ro.normalize_rows(c, "f16")
+    batches = [_corpus(Q, D, seed=92 + i) for i, Q in enumerate((200, 7, 256, 1, 130))]
+    batches[2][:50] = c[100:150]                       # some queries that are rows of the index
+    _lib.set_option("guard_force", force_widen)
+    try:
+        to_dev = (lambda a: torch.from_numpy(a).cuda()) if device_io else (lambda a: a)
+        pending = idx.query_begin(to_dev(batches[0]), k)
+        got = []
+        for b in batches[1:]:
+            res, pending = idx.query_next(pending, to_dev(b), k)
+            got.append(res)
+        got.append(pending.result())
+    finally:
+        _lib.set_option("guard_force", 0)
+    for b, (lab, dist, cnt) in zip(batches, got):
+        if device_io:
+            lab, dist, cnt = lab.cpu().numpy(), dist.cpu().numpy(), cnt.cpu().numpy()
+        ol, od, oc = ro.query(b, stored, labels, k)
+        np.testing.assert_array_equal(lab, ol)
+        np.testing.assert_array_equal(dist.view(np.uint32), od.view(np.uint32))
+        np.testing.assert_array_equal(cnt, oc)
+    _check(idx, ro, stored, labels, batches[1], k)      # and the index is free again
+
+
 def test_an_abandoned_query_handle_does_not_wedge_the_index(mods, tmp_path):
     """a query opened with query_begin whose handle is lost (an exception in the serving loop before
     result()) used to leave every other entry point refusing with MMISS_ERR_STATE until destroy. The handle now aborts the
