@@ -32,6 +32,16 @@ struct mmiss_index {
     // synchronisation and no copy-engine operation (round 3: four small device-to-host copies used to sit there, ~25 us).
     char* pin = nullptr;
     size_t pin_bytes = 0;
+    int32_t* swp_pin = nullptr;   // pinned: the widen pass's list lengths, written by the re-rank kernel itself (RerankArgs::cnt_host)
+    size_t swp_pin_n = 0;
+    int ensure_swp_pin(size_t n) {
+        if (n <= swp_pin_n) return MMISS_OK;
+        if (swp_pin) { MM_HIP(hipStreamSynchronize(stream())); MM_HIP(hipHostFree(swp_pin)); swp_pin = nullptr; swp_pin_n = 0; }
+        const size_t cap = n < 1024 ? 1024 : n * 2;
+        MM_HIP(hipHostMalloc(reinterpret_cast<void**>(&swp_pin), cap * 4, hipHostMallocDefault));
+        swp_pin_n = cap;
+        return MMISS_OK;
+    }
     int ensure_pin(size_t need) {
         if (need <= pin_bytes) return MMISS_OK;
         size_t cap = pin_bytes ? pin_bytes : 4096;
@@ -287,6 +297,7 @@ extern "C" int mmiss_index_destroy(mmiss_index* ix) {
     (void)hipDeviceSynchronize();
     if (ix->own_stream) (void)hipStreamDestroy(ix->own_stream);
     if (ix->pin) (void)hipHostFree(ix->pin);
+    if (ix->swp_pin) (void)hipHostFree(ix->swp_pin);
     if (ix->dist_pin) (void)hipHostFree(ix->dist_pin);
     if (ix->done_ev) (void)hipEventDestroy(ix->done_ev);
     delete ix;
@@ -762,10 +773,15 @@ int sweep_queries(mmiss_index* ix, hipStream_t st, const std::vector<int32_t>& w
     r.labels = ix->labels_d.as<int64_t>(); r.k = k;
     r.out_labels = d_lab; r.out_dist = d_dist; r.out_count = d_cnt;
     r.qmap = qmap_sw;
+    // the list lengths come back with the re-rank itself: every block stores its list's raw length into a pinned block (a copy
+    // into pageable memory behind the kernel was a second operation and a staged host copy in front of the next query's first
+    // launch: part of the ~87 us the GPU idled per pipelined step, round 6)
+    MM_TRY(ix->ensure_swp_pin((size_t)Qf));
+    r.cnt_host = ix->swp_pin;
     MM_TRY(launch_rerank(ix, st, r, Qf));
-    std::vector<int32_t> cnt((size_t)Qf);
-    MM_HIP(hipMemcpyAsync(cnt.data(), ix->swp_cnt.p, (size_t)Qf * 4, hipMemcpyDeviceToHost, st));
+    r.cnt_host = nullptr;
     MM_HIP(hipStreamSynchronize(st));
+    const int32_t* cnt = ix->swp_pin;
     ix->stat_rounds += 1;
     std::vector<int32_t> big_b, rest;   // blocks that need the large re-rank / original indices for the exhaustive pass
     int maxc = 1;

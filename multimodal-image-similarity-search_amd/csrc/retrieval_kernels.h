@@ -765,6 +765,9 @@ struct RerankArgs {
     const int32_t* cand_cnt;  // per-block candidate count (widen pass: the appended rows), null: ncand for every block
     const int32_t* bmap;      // block b reads candidate list / count bmap[b] (null: b)
     const float* inv;         // fp8 rows: inverse norm per row (f8_row_inv_kernel): canonical score = canon_dot x (double)inv[row]
+    // widen pass: block b also leaves its list's RAW length cand_cnt[lb] here — PINNED HOST memory, one plain store per block, as
+    // `flags` — so the host learns the lengths with the kernel's end instead of through a copy behind it (round 6); null: no
+    int32_t* cnt_host;
 };
 
 // The four partial sums of one lane of the canonical dot product (lane p of a row's 16: elements d = 4p + j + 64 i, i
@@ -817,7 +820,11 @@ __global__ __launch_bounds__(1024) void rerank_kernel(RerankArgs a) {
     const int q = a.qmap ? a.qmap[b] : b;
     const int lb = a.bmap ? a.bmap[b] : b;   // which candidate list
     int nc = a.ncand;                        // candidates of THIS block (block-uniform)
-    if (a.cand_cnt) { const int cc = a.cand_cnt[lb]; nc = cc < nc ? cc : nc; }
+    if (a.cand_cnt) {
+        const int cc = a.cand_cnt[lb];
+        if (a.cnt_host && tid == 0) a.cnt_host[b] = cc;
+        nc = cc < nc ? cc : nc;
+    }
     // sort buffer: npow2 entries of (dist f32, row i32), sized by the block's own candidate count (the launch provides LDS for
     // a.ncand): a widened query that collected 60 rows sorts 64 entries, not the launch's 1024
     int npow = 1;
